@@ -1,0 +1,103 @@
+// ORACLE — test infrastructure only (see jxo_common.h header).
+// Plain C entry points for ctypes (tests/, bench.py cpu_baseline leg, smoke()).
+#include "jxo_codec.h"
+#include <string>
+
+using namespace jxo;
+
+static thread_local std::string g_err;
+
+struct JxoImage { DecodeResult r; };
+struct JxoBytes { std::vector<uint8_t> b; };
+
+extern "C" {
+
+const char* jxo_last_error() { return g_err.c_str(); }
+
+JxoImage* jxo_decode(const uint8_t* data, size_t size, int num_threads, int want_dump) {
+  try {
+    JxoImage* im = new JxoImage();
+    DecodeOptions o;
+    o.num_threads = num_threads;
+    o.want_dump = want_dump != 0;
+    DecodeJxl(data, size, o, im->r);
+    return im;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+void jxo_image_free(JxoImage* im) { delete im; }
+void jxo_image_info(const JxoImage* im, int32_t* w, int32_t* h, int32_t* nch, int32_t* w8, int32_t* h8) {
+  *w = im->r.frame.xsize; *h = im->r.frame.ysize; *nch = im->r.num_channels;
+  *w8 = im->r.frame.xsize_blocks; *h8 = im->r.frame.ysize_blocks;
+}
+const uint8_t* jxo_image_pixels(const JxoImage* im) { return im->r.pixels.data(); }
+int32_t jxo_image_epf_iters(const JxoImage* im) { return im->r.frame.lf.epf_iters; }
+size_t jxo_image_exif(const JxoImage* im, const uint8_t** p) { *p = im->r.boxes.exif.data(); return im->r.boxes.exif.size(); }
+size_t jxo_image_xml(const JxoImage* im, const uint8_t** p) {
+  if (im->r.boxes.xml.empty()) { *p = nullptr; return 0; }
+  *p = im->r.boxes.xml[0].data();
+  return im->r.boxes.xml[0].size();
+}
+// name: lf_quant, lf, qcoef, xyb_idct, xyb_filtered (c = 0..2); strategy, raw_quant, sharpness, ytox, ytob, alpha (c ignored)
+// Returns element count, sets *ptr and *elem_size.
+size_t jxo_image_plane(const JxoImage* im, const char* name, int c, const void** ptr, int32_t* elem_size) {
+  const StageDump& d = im->r.dump;
+  std::string n(name);
+#define RET(v, es) do { *ptr = (v).data(); *elem_size = (es); return (v).size(); } while (0)
+  if (n == "lf_quant") RET(d.lf_quant[c], 4);
+  if (n == "lf") RET(d.lf[c], 4);
+  if (n == "qcoef") RET(d.qcoef[c], 4);
+  if (n == "xyb_idct") RET(d.xyb_idct[c], 4);
+  if (n == "xyb_filtered") RET(d.xyb_filtered[c], 4);
+  if (n == "strategy") RET(d.strategy, 1);
+  if (n == "raw_quant") RET(d.raw_quant, 4);
+  if (n == "sharpness") RET(d.sharpness, 1);
+  if (n == "ytox") RET(d.ytox, 1);
+  if (n == "ytob") RET(d.ytob, 1);
+  if (n == "alpha") RET(d.alpha, 4);
+#undef RET
+  *ptr = nullptr; *elem_size = 0;
+  return 0;
+}
+
+struct JxoEncodeParams {
+  float distance;
+  int32_t lossless;
+  int32_t effort;
+  int32_t strategy_mode;
+  int32_t fixed_strategy;
+  uint32_t seed;
+  int32_t epf_iters;
+  int32_t gaborish;
+  int32_t container;
+  int32_t adaptive_lf_smoothing;
+  int32_t lossless_predictor;
+  int32_t lossless_squeeze;
+  int32_t num_threads;
+};
+
+JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
+                     size_t exif_size, const uint8_t* xmp, size_t xmp_size) {
+  try {
+    EncodeParams p;
+    p.distance = ep->distance; p.lossless = ep->lossless != 0; p.effort = ep->effort;
+    p.strategy_mode = ep->strategy_mode; p.fixed_strategy = ep->fixed_strategy; p.seed = ep->seed;
+    p.epf_iters = ep->epf_iters; p.gaborish = ep->gaborish != 0; p.container = ep->container != 0;
+    p.adaptive_lf_smoothing = ep->adaptive_lf_smoothing != 0;
+    p.lossless_predictor = ep->lossless_predictor; p.lossless_squeeze = ep->lossless_squeeze != 0;
+    p.num_threads = ep->num_threads;
+    JxoBytes* b = new JxoBytes();
+    b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
+    return b;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return nullptr;
+  }
+}
+const uint8_t* jxo_bytes_data(const JxoBytes* b) { return b->b.data(); }
+size_t jxo_bytes_size(const JxoBytes* b) { return b->b.size(); }
+void jxo_bytes_free(JxoBytes* b) { delete b; }
+
+}  // extern "C"

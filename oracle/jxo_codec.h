@@ -1,0 +1,69 @@
+// ORACLE — test infrastructure only (see jxo_common.h header).
+// Public C++ surface of the CPU restatement: whole-file decode and encode.
+#pragma once
+#include "jxo_common.h"
+#include "jxo_headers.h"
+#include "jxo_vardct.h"
+#include <functional>
+
+namespace jxo {
+
+// Intermediate results kept for per-stage parity tests against the HIP path.
+// Plane layouts are the ones documented in DESIGN.md ("Data layout in HBM").
+struct StageDump {
+  int w8 = 0, h8 = 0;                      // frame size in 8x8 blocks
+  int wp = 0, hp = 0;                      // frame size padded to blocks (8*w8, 8*h8)
+  std::vector<int32_t> lf_quant[3];        // X,Y,B quantised LF, w8*h8
+  std::vector<float> lf[3];                // dequantised (+CfL, +smoothing) LF, w8*h8
+  std::vector<uint8_t> strategy;           // per 8x8 cell: strategy id | 0x80 if first (top-left) cell
+  std::vector<int32_t> raw_quant;          // per cell
+  std::vector<uint8_t> sharpness;          // per cell
+  std::vector<int8_t> ytox, ytob;          // per 64x64 tile, ceil(w8/8) x ceil(h8/8)
+  std::vector<int32_t> qcoef[3];           // quantised HF coefficients, footprint layout, wp*hp
+  std::vector<float> xyb_idct[3];          // after IDCT, wp*hp (cropped to frame size: w*h)
+  std::vector<float> xyb_filtered[3];      // after Gaborish + EPF, w*h
+  std::vector<int32_t> alpha;              // decoded alpha (w*h) if present
+};
+
+struct DecodeResult {
+  ImageMetadata meta;
+  FrameHeader frame;
+  ContainerInfo boxes;
+  int num_channels = 0;         // 1,2,3,4 (gray[+a], rgb[+a])
+  std::vector<uint8_t> pixels;  // interleaved u8, tight rows
+  StageDump dump;
+};
+
+struct DecodeOptions {
+  bool want_dump = false;
+  int num_threads = 1;
+};
+
+void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, DecodeResult& out);
+
+struct EncodeParams {
+  float distance = 1.0f;
+  bool lossless = false;
+  int effort = 7;
+  // 0: activity heuristic (default), 1: DCT8 only, 2: seeded pseudo-random mix of every supported
+  // strategy (parity-test coverage), 3: every block of one strategy (`fixed_strategy`) where it fits
+  int strategy_mode = 0;
+  int fixed_strategy = 0;
+  uint32_t seed = 1;
+  int epf_iters = -1;     // -1: by distance
+  bool gaborish = true;
+  bool container = true;
+  bool adaptive_lf_smoothing = true;
+  int lossless_predictor = 6;   // leaf predictor for lossless modular (6 = weighted)
+  bool lossless_squeeze = false;
+  int num_threads = 1;
+};
+
+// rgba: interleaved RGBA8 (or RGB8 / Gray8 / GrayA8 according to nch), tight rows.
+std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nch, const EncodeParams& p,
+                               const uint8_t* exif = nullptr, size_t exif_size = 0, const uint8_t* xmp = nullptr,
+                               size_t xmp_size = 0);
+
+void ParallelFor(int n, int num_threads, const std::function<void(int)>& fn);
+
+}  // namespace jxo

@@ -1,0 +1,592 @@
+// ORACLE — test infrastructure only (see jxo_common.h header).
+// A simple but complete JPEG XL encoder used to produce the .jxl fixtures/benchmark inputs
+// (the reference produces them through JxlEncoderAddImageFrame, Encoder/JxlEncoder.cpp:128).
+// Streams are single-frame, single-pass; lossy = VarDCT+XYB with lossless Modular alpha,
+// lossless = Modular RGB(A) with RCT.  Not a port of libjxl's heuristics.
+#include "jxo_codec.h"
+#include "jxo_entropy.h"
+#include "jxo_modular.h"
+
+namespace jxo {
+namespace {
+
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) {}
+  uint32_t Next() {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    return (uint32_t)(s >> 32);
+  }
+};
+
+static inline int Mirror(int v, int n) {
+  while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
+  return v;
+}
+
+// ------------------------------------------------------------------ global MA tree
+struct TreeBuilder {
+  Tree t;
+  int Leaf(int predictor) {
+    TreeNode n;
+    n.property = -1; n.predictor = predictor; n.offset = 0; n.multiplier = 1;
+    t.push_back(n);
+    return (int)t.size() - 1;
+  }
+  int Split(int prop, int32_t val, int gt, int le) {
+    TreeNode n;
+    n.property = prop; n.splitval = val; n.lchild = gt; n.rchild = le;
+    t.push_back(n);
+    return (int)t.size() - 1;
+  }
+};
+
+Tree MakeVarDctTree(uint32_t nlf) {
+  TreeBuilder b;
+  // alpha: gradient predictor, contexts by |W-NW| style local gradient magnitude (prop 10 signed => two splits)
+  int a_hi = b.Leaf(5), a_mid = b.Leaf(5), a_lo = b.Leaf(5);
+  int a1 = b.Split(10, -2, a_mid, a_lo);   // W-NW > -2 ? mid : lo
+  int alpha = b.Split(10, 1, a_hi, a1);    // W-NW > 1 ? hi : ...
+  // LF coefficients
+  int lf_b = b.Leaf(5), lf_x = b.Leaf(5), lf_y = b.Leaf(5);
+  int lf1 = b.Split(0, 0, lf_x, lf_y);
+  int lfn = b.Split(0, 1, lf_b, lf1);
+  // HF metadata
+  int sharp = b.Leaf(1), qrow = b.Leaf(1), srow = b.Leaf(0), cfl = b.Leaf(1);
+  int binfo = b.Split(2, 0, qrow, srow);
+  int m1 = b.Split(0, 1, binfo, cfl);
+  int meta = b.Split(0, 2, sharp, m1);
+  int a_global = b.Leaf(5);                       // alpha coded in the GlobalModular section (stream 0)
+  int n2 = b.Split(1, 0, lfn, a_global);
+  int n1 = b.Split(1, (int32_t)(2 * nlf), meta, n2);
+  int root = b.Split(1, (int32_t)(3 * nlf + kNumQuantTables), alpha, n1);
+  return MakeBfsTree(b.t, root);
+}
+
+Tree MakeLosslessTree(int predictor) {
+  TreeBuilder b;
+  // contexts from the weighted predictor's max error (property 15), symmetric buckets
+  static const int32_t cuts[] = {-80, -24, -8, -3, -1, 0, 2, 7, 23, 79};
+  const int ncut = sizeof(cuts) / sizeof(cuts[0]);
+  // build a right-leaning chain: prop15 > cuts[i] ? ... (balanced enough for 11 leaves)
+  std::function<int(int, int)> build = [&](int lo, int hi) -> int {  // leaves for cut range [lo,hi)
+    if (lo == hi) return b.Leaf(predictor);
+    int mid = (lo + hi) / 2;
+    int gt = build(mid + 1, hi);
+    int le = build(lo, mid);
+    return b.Split(15, cuts[mid], gt, le);
+  };
+  int root = build(0, ncut);
+  return MakeBfsTree(b.t, root);
+}
+
+// ------------------------------------------------------------------ section assembly
+struct SectionWriter {
+  std::vector<BitWriter> sec;
+};
+
+std::vector<uint8_t> AssembleFrame(const ImageMetadata& m, const FrameHeader& f, std::vector<BitWriter>& sections) {
+  BitWriter bw;
+  WriteFrameHeader(bw, m, f);
+  std::vector<uint32_t> sizes;
+  std::vector<std::vector<uint8_t>> bytes;
+  if (f.NumTocEntries() == 1) {
+    BitWriter all;
+    for (auto& s : sections) all.Append(s);
+    bytes.push_back(all.Finish());
+  } else {
+    for (auto& s : sections) bytes.push_back(s.Finish());
+  }
+  for (auto& b : bytes) sizes.push_back((uint32_t)b.size());
+  JXO_CHECK(sizes.size() == f.NumTocEntries(), "section count");
+  WriteToc(bw, sizes);
+  for (auto& b : bytes) bw.AppendBytes(b.data(), b.size());
+  return bw.Finish();
+}
+
+// ------------------------------------------------------------------ VarDCT
+struct VarDctEncoder {
+  const EncodeParams& p;
+  ImageMetadata m;
+  FrameHeader f;
+  int w, h, w8, h8, wp, hp, wt, ht;
+  Plane xyb[3];              // padded
+  std::vector<uint8_t> strategy;  // per cell, 0x80 = first
+  std::vector<int32_t> raw_quant;
+  uint32_t global_scale, quant_lf;
+  DequantMatrices dq;
+  BlockCtxMap bctx;
+  std::vector<int32_t> lfq[3];
+  std::vector<int32_t> alpha;
+  bool has_alpha;
+
+  VarDctEncoder(const EncodeParams& p_) : p(p_) {}
+
+  void ChooseStrategies() {
+    strategy.assign((size_t)w8 * h8, 0xFF);
+    // per-cell activity from Y
+    std::vector<float> act((size_t)w8 * h8);
+    for (int by = 0; by < h8; by++)
+      for (int bx = 0; bx < w8; bx++) {
+        double s = 0, s2 = 0;
+        for (int y = 0; y < 8; y++)
+          for (int x = 0; x < 8; x++) {
+            float v = xyb[1].Row(by * 8 + y)[bx * 8 + x];
+            s += v; s2 += (double)v * v;
+          }
+        double var = s2 / 64 - (s / 64) * (s / 64);
+        act[(size_t)by * w8 + bx] = (float)std::sqrt(std::max(0.0, var));
+      }
+    auto fits = [&](int bx, int by, int s) {
+      int cx = kCoveredX[s], cy = kCoveredY[s];
+      if (bx % cx || by % cy) return false;
+      if (bx + cx > w8 || by + cy > h8) return false;
+      if ((bx % 32) + cx > 32 || (by % 32) + cy > 32) return false;
+      for (int iy = 0; iy < cy; iy++)
+        for (int ix = 0; ix < cx; ix++)
+          if (strategy[(size_t)(by + iy) * w8 + bx + ix] != 0xFF) return false;
+      return true;
+    };
+    auto place = [&](int bx, int by, int s) {
+      int cx = kCoveredX[s], cy = kCoveredY[s];
+      for (int iy = 0; iy < cy; iy++)
+        for (int ix = 0; ix < cx; ix++) strategy[(size_t)(by + iy) * w8 + bx + ix] = (uint8_t)s;
+      strategy[(size_t)by * w8 + bx] = (uint8_t)(s | 0x80);
+    };
+    auto max_act = [&](int bx, int by, int cx, int cy) {
+      float mx = 0;
+      for (int iy = 0; iy < cy; iy++)
+        for (int ix = 0; ix < cx; ix++) mx = std::max(mx, act[(size_t)(by + iy) * w8 + bx + ix]);
+      return mx;
+    };
+    static const int kAll[] = {DCT8, IDENTITY, DCT2X2, DCT4X4, DCT16X16, DCT32X32, DCT16X8, DCT8X16, DCT32X8, DCT8X32, DCT32X16,
+                               DCT16X32, DCT4X8, DCT8X4, DCT64X64, DCT64X32, DCT32X64, DCT128X128, DCT128X64, DCT64X128,
+                               DCT256X256, DCT256X128, DCT128X256};
+    const int nall = sizeof(kAll) / sizeof(kAll[0]);
+    Rng rng(p.seed);
+    for (int by = 0; by < h8; by++)
+      for (int bx = 0; bx < w8; bx++) {
+        if (strategy[(size_t)by * w8 + bx] != 0xFF) continue;
+        int s = DCT8;
+        if (p.strategy_mode == 1) {
+          s = DCT8;
+        } else if (p.strategy_mode == 3) {
+          s = fits(bx, by, p.fixed_strategy) ? p.fixed_strategy : DCT8;
+        } else if (p.strategy_mode == 2) {
+          // bias towards small transforms so large ones do not eat the whole frame
+          uint32_t r = rng.Next();
+          int cand = kAll[r % nall];
+          int area = kCoveredX[cand] * kCoveredY[cand];
+          if (area >= 256 && (rng.Next() % 4)) cand = kAll[rng.Next() % 14];
+          s = fits(bx, by, cand) ? cand : DCT8;
+        } else {
+          static const struct { int s; float t; } kTry[] = {{DCT64X64, 0.0035f}, {DCT64X32, 0.0045f}, {DCT32X64, 0.0045f},
+                                                           {DCT32X32, 0.007f},  {DCT32X16, 0.009f},  {DCT16X32, 0.009f},
+                                                           {DCT16X16, 0.016f},  {DCT16X8, 0.024f},   {DCT8X16, 0.024f}};
+          for (auto& t : kTry)
+            if (fits(bx, by, t.s) && max_act(bx, by, kCoveredX[t.s], kCoveredY[t.s]) < t.t) { s = t.s; break; }
+        }
+        place(bx, by, s);
+      }
+    // quant field: finer in flat areas
+    raw_quant.assign((size_t)w8 * h8, 16);
+    for (int by = 0; by < h8; by++)
+      for (int bx = 0; bx < w8; bx++) {
+        size_t cell = (size_t)by * w8 + bx;
+        if (!(strategy[cell] & 0x80)) continue;
+        int s = strategy[cell] & 0x7F, cx = kCoveredX[s], cy = kCoveredY[s];
+        double a = 0;
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) a += act[cell + (size_t)iy * w8 + ix];
+        a /= cx * cy;
+        double mod = 0.7 + 0.8 / (1.0 + a / 0.012);
+        int q = (int)std::lrint(16.0 * mod);
+        q = std::max(1, std::min(256, q));
+        for (int iy = 0; iy < cy; iy++) for (int ix = 0; ix < cx; ix++) raw_quant[cell + (size_t)iy * w8 + ix] = q;
+      }
+  }
+
+  std::vector<uint8_t> Encode(const uint8_t* px, int nch) {
+    w = m.xsize; h = m.ysize;
+    f.Derive(m);
+    w8 = f.xsize_blocks; h8 = f.ysize_blocks; wp = w8 * 8; hp = h8 * 8;
+    wt = (int)DivCeil(w8, 8); ht = (int)DivCeil(h8, 8);
+    const int ncolor = nch >= 3 ? 3 : 1;
+    has_alpha = nch == 2 || nch == 4;
+    // 1. sRGB8 -> linear -> XYB
+    Plane img[3] = {Plane(w, h), Plane(w, h), Plane(w, h)};
+    float lut[256];
+    for (int i = 0; i < 256; i++) lut[i] = SrgbToLinear(i / 255.0f);
+    if (has_alpha) alpha.resize((size_t)w * h);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        const uint8_t* s = px + ((size_t)y * w + x) * nch;
+        for (int c = 0; c < 3; c++) img[c].Row(y)[x] = lut[s[ncolor == 3 ? c : 0]];
+        if (has_alpha) alpha[(size_t)y * w + x] = s[ncolor];
+      }
+    LinearToXyb(img);
+    // 2. approximate inverse of the decoder-side Gaborish: 2*I - K
+    if (f.lf.gab) {
+      Plane blur[3] = {img[0], img[1], img[2]};
+      Gaborish(blur, f.lf);
+      for (int c = 0; c < 3; c++)
+        for (size_t i = 0; i < img[c].d.size(); i++) img[c].d[i] = 2 * img[c].d[i] - blur[c].d[i];
+    }
+    for (int c = 0; c < 3; c++) {
+      xyb[c] = Plane(wp, hp);
+      for (int y = 0; y < hp; y++)
+        for (int x = 0; x < wp; x++) xyb[c].Row(y)[x] = img[c].Row(std::min(y, h - 1))[std::min(x, w - 1)];
+    }
+    // 3. quantiser
+    double qf = 0.85 / std::max(0.05f, p.distance);
+    global_scale = (uint32_t)std::max<long>(1, std::min<long>(8193 + 65535, std::lrint(65536.0 * qf / 16.0)));
+    double lfq_f = 1.1 / std::max(0.05f, p.distance);
+    quant_lf = (uint32_t)std::max<long>(1, std::min<long>(65536, std::lrint(lfq_f * 65536.0 / global_scale)));
+    dq.SetDefault();
+    bctx.SetDefault();
+    ChooseStrategies();
+    const float inv_gs = 65536.0f / global_scale;
+    const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+    float mul_lf[3];
+    for (int c = 0; c < 3; c++) mul_lf[c] = m_lf[c] * inv_gs / quant_lf;
+    // 4. transforms, LF, quantised AC (kept per varblock)
+    const size_t ncell = (size_t)w8 * h8;
+    for (int c = 0; c < 3; c++) lfq[c].assign(ncell, 0);
+    std::vector<std::vector<int32_t>> qac[3];  // per cell (first cells only): quantised block in stored layout
+    for (int c = 0; c < 3; c++) qac[c].resize(ncell);
+    const float xmul = std::pow(0.8f, (float)f.x_qm_scale - 2.0f), bmul = std::pow(0.8f, (float)f.b_qm_scale - 2.0f);
+    const float base_b = 1.0f;
+    ParallelFor(h8, p.num_threads, [&](int by) {
+      std::vector<float> coef[3], lfv;
+      for (int bx = 0; bx < w8; bx++) {
+        size_t cell = (size_t)by * w8 + bx;
+        if (!(strategy[cell] & 0x80)) continue;
+        int s = strategy[cell] & 0x7F, cx = kCoveredX[s], cy = kCoveredY[s];
+        size_t size = (size_t)cx * cy * 64;
+        float lfs[3][1024];
+        for (int c = 0; c < 3; c++) {
+          coef[c].resize(size);
+          ForwardTransform(s, xyb[c].Row(by * 8) + bx * 8, wp, coef[c].data());
+          LfFromLlf(s, coef[c].data(), lfs[c], cx);
+        }
+        // LF quantisation (Y first; X and B code the residual after LF chroma-from-luma)
+        for (int iy = 0; iy < cy; iy++)
+          for (int ix = 0; ix < cx; ix++) {
+            size_t cc = cell + (size_t)iy * w8 + ix;
+            int32_t qy = (int32_t)std::lrint(lfs[1][iy * cx + ix] / mul_lf[1]);
+            float fy = qy * mul_lf[1];
+            lfq[1][cc] = qy;
+            lfq[0][cc] = (int32_t)std::lrint(lfs[0][iy * cx + ix] / mul_lf[0]);
+            lfq[2][cc] = (int32_t)std::lrint((lfs[2][iy * cx + ix] - base_b * fy) / mul_lf[2]);
+          }
+        // AC quantisation
+        const float scale = inv_gs / raw_quant[cell];
+        const float dqs[3] = {scale * xmul, scale, scale * bmul};
+        const float cfl[3] = {0.f, 0.f, base_b};
+        std::vector<float> yd(size);
+        for (int c : {1, 0, 2}) {
+          const float* wq = dq.Get(s, c);
+          std::vector<int32_t>& q = qac[c][cell];
+          q.assign(size, 0);
+          for (size_t k = 0; k < size; k++) {
+            float target = coef[c][k];
+            if (c != 1) target -= cfl[c] * yd[k];
+            float v = target / (dqs[c] * wq[k]);
+            float a = std::fabs(v);
+            int32_t qi = a < 0.6f ? 0 : (int32_t)std::lrint(v);
+            q[k] = qi;
+            if (c == 1) {
+              float adj = qi == 0 ? 0 : (std::abs(qi) == 1 ? (qi > 0 ? m.quant_bias[1] : -m.quant_bias[1]) : qi - m.quant_bias[3] / qi);
+              yd[k] = adj * dqs[1] * wq[k];
+            }
+          }
+        }
+      }
+    });
+    // 5. tokens
+    const uint32_t nlf = f.num_lf_groups, ng = f.num_groups;
+    Tree tree = MakeVarDctTree(nlf);
+    WPHeader wp_default;
+    std::vector<std::vector<Token>> lf_tok(nlf), meta_tok(nlf), alpha_tok(ng), ac_tok(ng);
+    std::vector<uint32_t> nb_blocks(nlf);
+    ParallelFor((int)nlf, p.num_threads, [&](int g) {
+      int gx = g % f.xsize_lf_groups, gy = g / f.xsize_lf_groups;
+      int bx0 = gx * (int)f.group_dim, by0 = gy * (int)f.group_dim;
+      int bw = std::min((int)f.group_dim, w8 - bx0), bh = std::min((int)f.group_dim, h8 - by0);
+      ModularImage img;
+      for (int c = 0; c < 3; c++) img.ch.emplace_back(bw, bh, 0, 0);
+      const int chan_of[3] = {1, 0, 2};  // modular channel order Y, X, B
+      for (int mc = 0; mc < 3; mc++)
+        for (int y = 0; y < bh; y++)
+          for (int x = 0; x < bw; x++) img.ch[mc].Row(y)[x] = lfq[chan_of[mc]][(size_t)(by0 + y) * w8 + bx0 + x];
+      for (int mc = 0; mc < 3; mc++) TokenizeChannel(tree, wp_default, img, mc, 1 + g, lf_tok[g]);
+      // HF metadata
+      std::vector<int32_t> srow, qrow;
+      for (int y = 0; y < bh; y++)
+        for (int x = 0; x < bw; x++) {
+          size_t cell = (size_t)(by0 + y) * w8 + bx0 + x;
+          if (!(strategy[cell] & 0x80)) continue;
+          srow.push_back(strategy[cell] & 0x7F);
+          qrow.push_back(raw_quant[cell] - 1);
+        }
+      nb_blocks[g] = (uint32_t)srow.size();
+      int tw = (int)DivCeil(bw, 8), th = (int)DivCeil(bh, 8);
+      ModularImage mi;
+      mi.ch.emplace_back(tw, th, 0, 0);
+      mi.ch.emplace_back(tw, th, 0, 0);
+      mi.ch.emplace_back((int)srow.size(), 2, 0, 0);
+      mi.ch.emplace_back(bw, bh, 0, 0);
+      memcpy(mi.ch[2].Row(0), srow.data(), srow.size() * 4);
+      memcpy(mi.ch[2].Row(1), qrow.data(), qrow.size() * 4);
+      for (auto& v : mi.ch[3].d) v = 4;  // EPF sharpness
+      for (int mc = 0; mc < 4; mc++) TokenizeChannel(tree, wp_default, mi, mc, 1 + 2 * nlf + g, meta_tok[g]);
+    });
+    ParallelFor((int)ng, p.num_threads, [&](int g) {
+      int gx = g % f.xsize_groups, gy = g / f.xsize_groups;
+      // AC tokens
+      const int bx0 = gx * 32, by0 = gy * 32;
+      const int bw = std::min(32, w8 - bx0), bh = std::min(32, h8 - by0);
+      uint8_t nz[3][32 * 32];
+      memset(nz, 0, sizeof(nz));
+      std::vector<Token>& out = ac_tok[g];
+      for (int by = 0; by < bh; by++)
+        for (int bx = 0; bx < bw; bx++) {
+          size_t cell = (size_t)(by0 + by) * w8 + bx0 + bx;
+          if (!(strategy[cell] & 0x80)) continue;
+          int s = strategy[cell] & 0x7F, cx = kCoveredX[s], cy = kCoveredY[s];
+          uint32_t covered = cx * cy, log2c = CeilLog2(covered), size = covered * 64;
+          uint32_t ord = kStrategyOrder[s];
+          const uint32_t* ordp = NaturalOrder(s).data();
+          for (int c : {1, 0, 2}) {
+            const std::vector<int32_t>& q = qac[c][cell];
+            uint32_t nzeros = 0;
+            for (uint32_t k = covered; k < size; k++) nzeros += q[ordp[k]] != 0;
+            uint32_t predicted;
+            const uint8_t* row = nz[c] + by * 32;
+            if (bx == 0) predicted = by == 0 ? 32 : row[-32 + bx];
+            else if (by == 0) predicted = row[bx - 1];
+            else predicted = (row[-32 + bx] + row[bx - 1] + 1) / 2;
+            uint32_t block_ctx = bctx.Context(0, raw_quant[cell], ord, c);
+            out.emplace_back(bctx.NonZeroContext(predicted, block_ctx), nzeros);
+            uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
+            for (int iy = 0; iy < cy; iy++)
+              for (int ix = 0; ix < cx; ix++) nz[c][(by + iy) * 32 + bx + ix] = fill;
+            const uint32_t histo_offset = bctx.ZeroDensityContextsOffset(block_ctx);
+            uint32_t prev = nzeros > size / 16 ? 0 : 1;
+            for (uint32_t k = covered; k < size && nzeros != 0; k++) {
+              uint32_t ctx = histo_offset + ZeroDensityContext(nzeros, k, covered, log2c, prev);
+              uint32_t u = (uint32_t)PackSigned(q[ordp[k]]);
+              out.emplace_back(ctx, u);
+              prev = u != 0;
+              nzeros -= prev;
+            }
+          }
+        }
+      // alpha tokens
+      if (has_alpha) {
+        int x0 = gx * f.group_dim, y0 = gy * f.group_dim;
+        int gw = std::min<int>(f.group_dim, w - x0), gh = std::min<int>(f.group_dim, h - y0);
+        ModularImage ai;
+        ai.ch.emplace_back(gw, gh, 0, 0);
+        for (int y = 0; y < gh; y++) memcpy(ai.ch[0].Row(y), &alpha[(size_t)(y0 + y) * w + x0], sizeof(int32_t) * gw);
+        const bool global = w <= (int)f.group_dim && h <= (int)f.group_dim;
+        uint32_t sid = global ? 0 : 1 + 3 * nlf + kNumQuantTables + g;
+        TokenizeChannel(tree, wp_default, ai, 0, sid, alpha_tok[g]);
+      }
+    });
+    // 6. write sections
+    const bool single = f.NumTocEntries() == 1;
+    const bool alpha_global = has_alpha && w <= (int)f.group_dim && h <= (int)f.group_dim;
+    std::vector<BitWriter> sec(single ? 4 : 2 + nlf + ng);
+    // --- LfGlobal
+    BitWriter& g0 = sec[0];
+    g0.Bool(true);  // LF dequant defaults
+    g0.U32(BitsOff(11, 1), BitsOff(11, 2049), BitsOff(12, 4097), BitsOff(16, 8193), global_scale);
+    g0.U32(Val(16), BitsOff(5, 1), BitsOff(8, 1), BitsOff(16, 1), quant_lf);
+    g0.Bool(true);  // default block context map
+    g0.Bool(true);  // default LF chroma-from-luma
+    g0.Bool(true);  // has global tree
+    WriteTree(g0, tree);
+    std::vector<const std::vector<Token>*> sets;
+    for (auto& t : lf_tok) sets.push_back(&t);
+    for (auto& t : meta_tok) sets.push_back(&t);
+    for (auto& t : alpha_tok) sets.push_back(&t);
+    EncOptions mo;
+    mo.max_clusters = 32;
+    EncCode mcode;
+    BuildAndWriteCode(sets, (tree.size() + 1) / 2, mo, g0, mcode);
+    GroupHeader gh;
+    gh.use_global_tree = true;
+    if (has_alpha) {
+      // global modular image: header always; channel data only when it fits one group
+      WriteGroupHeader(g0, gh);
+      if (alpha_global) WriteTokens(alpha_tok[0], mcode, g0);
+    }
+    // --- LfGroups
+    for (uint32_t g = 0; g < nlf; g++) {
+      BitWriter& s = sec[1 + g];
+      int gx = g % f.xsize_lf_groups, gy = g / f.xsize_lf_groups;
+      int bw = std::min((int)f.group_dim, w8 - gx * (int)f.group_dim), bh = std::min((int)f.group_dim, h8 - gy * (int)f.group_dim);
+      s.Write(2, 0);  // extra_precision
+      WriteGroupHeader(s, gh);
+      WriteTokens(lf_tok[g], mcode, s);
+      s.Write(CeilLog2((uint64_t)bw * bh), nb_blocks[g] - 1);
+      WriteGroupHeader(s, gh);
+      WriteTokens(meta_tok[g], mcode, s);
+    }
+    // --- HfGlobal
+    BitWriter& hg = sec[1 + nlf];
+    hg.Bool(true);                          // default dequant matrices
+    hg.Write(CeilLog2(ng), 0);              // num_hf_presets - 1
+    hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);  // used_orders: none
+    std::vector<const std::vector<Token>*> acsets;
+    for (auto& t : ac_tok) acsets.push_back(&t);
+    EncOptions ao;
+    ao.max_clusters = 96;
+    EncCode acode;
+    BuildAndWriteCode(acsets, bctx.NumAcContexts(), ao, hg, acode);
+    // --- PassGroups
+    for (uint32_t g = 0; g < ng; g++) {
+      BitWriter& s = sec[2 + nlf + g];
+      WriteTokens(ac_tok[g], acode, s);
+      if (has_alpha && !alpha_global) {
+        WriteGroupHeader(s, gh);
+        WriteTokens(alpha_tok[g], mcode, s);
+      }
+    }
+    return AssembleFrame(m, f, sec);
+  }
+};
+
+// ------------------------------------------------------------------ lossless Modular
+std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f, const uint8_t* px, int nch, const EncodeParams& p) {
+  f.encoding = 1;
+  f.group_size_shift = 1;
+  f.lf.gab = false;
+  f.lf.epf_iters = 0;
+  f.Derive(m);
+  const int w = m.xsize, h = m.ysize;
+  const int ncolor = nch >= 3 ? 3 : 1;
+  ModularImage full;
+  for (int c = 0; c < nch; c++) {
+    full.ch.emplace_back(w, h, 0, 0);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) full.ch[c].Row(y)[x] = px[((size_t)y * w + x) * nch + c];
+  }
+  GroupHeader gh_global;
+  gh_global.use_global_tree = true;
+  if (ncolor == 3) ForwardRCT(full, 0, 6);
+  if (p.lossless_squeeze) {
+    std::vector<SqueezeParams> sp;
+    DefaultSqueezeParams(full, sp);
+    ForwardSqueeze(full, sp);
+  }
+  gh_global.transforms = full.transforms;
+  Tree tree = MakeLosslessTree(p.lossless_predictor);
+  WPHeader wph;
+  const uint32_t nlf = f.num_lf_groups, ng = f.num_groups;
+  const int gd = f.group_dim;
+  // which channels are coded globally
+  size_t first_group_channel = 0;
+  for (; first_group_channel < full.ch.size(); first_group_channel++)
+    if (full.ch[first_group_channel].w > gd || full.ch[first_group_channel].h > gd) break;
+  std::vector<Token> global_tok;
+  for (size_t c = 0; c < first_group_channel; c++) TokenizeChannel(tree, wph, full, (int)c, 0, global_tok);
+  auto group_tokens = [&](int x0, int y0, int xs, int ys, int min_shift, int max_shift, uint32_t sid, std::vector<Token>& out) -> bool {
+    ModularImage sub;
+    for (size_t c = first_group_channel; c < full.ch.size(); c++) {
+      const Channel& fc = full.ch[c];
+      if (!fc.w || !fc.h) continue;
+      int shift = std::min(fc.hshift, fc.vshift);
+      if (shift > max_shift || shift < min_shift) continue;
+      int rx = x0 >> fc.hshift, ry = y0 >> fc.vshift, rw = xs >> fc.hshift, rh = ys >> fc.vshift;
+      rw = std::max(0, std::min(rw, fc.w - rx));
+      rh = std::max(0, std::min(rh, fc.h - ry));
+      if (rw <= 0 || rh <= 0) continue;
+      Channel ch(rw, rh, fc.hshift, fc.vshift);
+      for (int y = 0; y < rh; y++) memcpy(ch.Row(y), fc.Row(ry + y) + rx, sizeof(int32_t) * rw);
+      sub.ch.push_back(ch);
+    }
+    if (sub.ch.empty()) return false;
+    for (size_t c = 0; c < sub.ch.size(); c++) TokenizeChannel(tree, wph, sub, (int)c, sid, out);
+    return true;
+  };
+  std::vector<std::vector<Token>> lf_tok(nlf), ac_tok(ng);
+  std::vector<uint8_t> lf_has(nlf, 0), ac_has(ng, 0);
+  ParallelFor((int)nlf, p.num_threads, [&](int g) {
+    int gx = g % f.xsize_lf_groups, gy = g / f.xsize_lf_groups;
+    lf_has[g] = group_tokens(gx * gd * 8, gy * gd * 8, gd * 8, gd * 8, 3, 1000, 1 + nlf + g, lf_tok[g]);
+  });
+  ParallelFor((int)ng, p.num_threads, [&](int g) {
+    int gx = g % f.xsize_groups, gy = g / f.xsize_groups;
+    ac_has[g] = group_tokens(gx * gd, gy * gd, gd, gd, 0, 2, 1 + 3 * nlf + kNumQuantTables + g, ac_tok[g]);
+  });
+  const bool single = f.NumTocEntries() == 1;
+  std::vector<BitWriter> sec(single ? 4 : 2 + nlf + ng);
+  BitWriter& g0 = sec[0];
+  g0.Bool(true);  // LF dequant defaults
+  g0.Bool(true);  // global tree
+  WriteTree(g0, tree);
+  std::vector<const std::vector<Token>*> sets = {&global_tok};
+  for (auto& t : lf_tok) sets.push_back(&t);
+  for (auto& t : ac_tok) sets.push_back(&t);
+  EncOptions mo;
+  mo.max_clusters = 64;
+  EncCode mcode;
+  BuildAndWriteCode(sets, (tree.size() + 1) / 2, mo, g0, mcode);
+  WriteGroupHeader(g0, gh_global);
+  if (first_group_channel > 0) WriteTokens(global_tok, mcode, g0);
+  GroupHeader gh;
+  gh.use_global_tree = true;
+  for (uint32_t g = 0; g < nlf; g++)
+    if (lf_has[g]) { WriteGroupHeader(sec[1 + g], gh); WriteTokens(lf_tok[g], mcode, sec[1 + g]); }
+  for (uint32_t g = 0; g < ng; g++)
+    if (ac_has[g]) { WriteGroupHeader(sec[2 + nlf + g], gh); WriteTokens(ac_tok[g], mcode, sec[2 + nlf + g]); }
+  return AssembleFrame(m, f, sec);
+}
+
+}  // namespace
+
+std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nch, const EncodeParams& p, const uint8_t* exif,
+                               size_t exif_size, const uint8_t* xmp, size_t xmp_size) {
+  JXO_CHECK(nch >= 1 && nch <= 4 && w > 0 && h > 0, "bad image");
+  ImageMetadata m;
+  m.xsize = w; m.ysize = h;
+  m.xyb_encoded = !p.lossless;
+  // The reference always signals sRGB with perceptual intent (Encoder/JxlEncoder.cpp:269-282).
+  m.color.all_default = false;
+  m.color.color_space = nch >= 3 ? 0 : 1;
+  m.color.white_point = 1; m.color.primaries = 1; m.color.tf = 13; m.color.rendering_intent = 0;
+  if (nch == 2 || nch == 4) m.ec.push_back(ExtraChannelInfo());
+  FrameHeader f;
+  f.ec_upsampling.assign(m.ec.size(), 1);
+  std::vector<uint8_t> frame;
+  if (p.lossless) {
+    frame = EncodeLosslessFrame(m, f, px, nch, p);
+  } else {
+    f.encoding = 0;
+    f.lf.gab = p.gaborish;
+    int iters = p.epf_iters;
+    if (iters < 0) {
+      iters = 0;
+      for (float t : {0.7f, 1.5f, 4.0f}) if (p.distance >= t) iters++;
+    }
+    f.lf.epf_iters = iters;
+    if (!p.adaptive_lf_smoothing) f.flags |= FrameHeader::kSkipAdaptiveLfSmoothing;
+    VarDctEncoder enc(p);
+    enc.m = m;
+    enc.f = f;
+    frame = enc.Encode(px, nch);
+  }
+  BitWriter bw;
+  bw.Write(8, 0xFF);
+  bw.Write(8, 0x0A);
+  WriteSizeHeader(bw, w, h);
+  WriteImageMetadata(bw, m);
+  bw.AlignByte();
+  std::vector<uint8_t> cs = bw.Finish();
+  cs.insert(cs.end(), frame.begin(), frame.end());
+  if (!p.container) return cs;
+  return WriteContainer(cs, exif, exif_size, xmp, xmp_size);
+}
+
+}  // namespace jxo

@@ -101,3 +101,21 @@ size_t jxo_bytes_size(const JxoBytes* b) { return b->b.size(); }
 void jxo_bytes_free(JxoBytes* b) { delete b; }
 
 }  // extern "C"
+
+// ---- table introspection for host-logic tests
+extern "C" {
+size_t jxo_natural_order(int strategy, uint32_t* dst, size_t capacity) {
+  const std::vector<uint32_t>& o = NaturalOrder(strategy);
+  for (size_t i = 0; i < o.size() && i < capacity; i++) dst[i] = o[i];
+  return o.size();
+}
+size_t jxo_dequant_table(int strategy, int c, float* dst, size_t capacity) {
+  static DequantMatrices dq;
+  static bool init = false;
+  if (!init) { dq.SetDefault(); init = true; }
+  int q = kStrategyQuantTable[strategy];
+  const float* p = dq.Get(strategy, c);
+  for (size_t i = 0; i < dq.n[q] && i < capacity; i++) dst[i] = p[i];
+  return dq.n[q];
+}
+}

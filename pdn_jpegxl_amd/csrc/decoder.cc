@@ -1,0 +1,752 @@
+// Host orchestration of the HIP decode path and the C-ABI (include/jxlfiletypeio.h).
+//
+// LoadImage mirrors DecoderReadImage (reference: src/JxlFileTypeIO/Decoder/JxlDecoder.cpp:796-852):
+// pass 1 = headers + metadata callbacks (:412-793), pass 2 = frame -> one interleaved buffer ->
+// setLayerData (:217-410).  The arithmetic that the reference delegates to libjxl
+// (JxlDecoderProcessInput, :252) runs in the kernels of kernels.hip.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/jxlfiletypeio.h"
+#include "host_parse.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string& m) : std::runtime_error(m) {}
+};
+#define HIP_OK(expr)                                                                                      \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(e_));              \
+  } while (0)
+
+static void SetErr(ErrorInfo* e, const char* fmt, ...) {
+  if (!e) return;
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  int n = vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  // reference semantics (Common.cpp:18-53): only messages of 1..255 chars are stored
+  if (n > 0 && n <= 255) memcpy(e->errorMessage, buf, (size_t)n + 1);
+  else if (n > 255) { memcpy(e->errorMessage, buf, 255); e->errorMessage[255] = 0; }
+}
+
+static inline size_t Align(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Bump {
+  size_t off = 0;
+  size_t Take(size_t bytes, size_t align = 256) {
+    off = Align(off, align);
+    size_t r = off;
+    off += bytes;
+    return r;
+  }
+};
+
+struct StageTimer {
+  std::vector<const char*> names;
+  std::vector<hipEvent_t> ev;
+};
+
+}  // namespace jxlhip
+
+using namespace jxlhip;
+
+struct JxlHipDecoder {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  // static tables
+  float* d_basis_all = nullptr;
+  float* d_basis_small = nullptr;
+  float* d_llf_scale = nullptr;
+  uint16_t* d_natural[kNumOrders] = {};
+  float* d_dq[kNumQuantTables] = {};
+  uint32_t dq_n[kNumQuantTables] = {};
+  // grow-only buffers
+  uint8_t* d_ws = nullptr; size_t ws_cap = 0;        // planes
+  uint8_t* d_blob = nullptr; size_t blob_cap = 0;    // tables / descriptors / uploaded bitstreams
+  uint8_t* h_blob = nullptr; size_t h_blob_cap = 0;  // pinned mirror of d_blob
+  uint32_t* h_status = nullptr; size_t h_status_cap = 0;
+  // last batch
+  int n = 0;
+  std::vector<ParsedFrame> frames;
+  std::vector<DevImage> imgs;          // host copies (device pointers inside)
+  std::vector<int> parse_status;
+  std::vector<std::string> parse_msg;
+  std::vector<size_t> status_off;      // offset of each image's status words in the workspace
+  DevImage* d_imgs = nullptr;
+  hipStream_t last_stream = nullptr;
+  bool pending = false;
+  // options
+  int lane_stride_override = 0;
+  bool debug_taps = false;
+  struct Tap { std::vector<uint8_t> qcoef[3], xyb_idct[3], xyb_filtered[3]; };
+  std::vector<Tap> taps;
+  // timing
+  std::vector<std::string> stage_names;
+  std::vector<hipEvent_t> events;
+  std::vector<float> stage_ms;
+
+  explicit JxlHipDecoder(int dev);
+  ~JxlHipDecoder();
+  void EnsureWs(size_t bytes);
+  void EnsureBlob(size_t bytes);
+  void Mark(const char* name, hipStream_t s);
+  void Decode(int32_t n_, const uint8_t* const* host_data, const size_t* sizes, const uint8_t* const* dev_data,
+              uint8_t* const* dev_out, hipStream_t stream, bool sync, DecoderStatus* statuses, ErrorInfo* err);
+  DecoderStatus Finish(DecoderStatus* statuses, ErrorInfo* err);
+  void CopyPlaneTap(int stage);
+};
+
+JxlHipDecoder::JxlHipDecoder(int dev) {
+  if (dev < 0) HIP_OK(hipGetDevice(&dev));
+  device = dev;
+  HIP_OK(hipSetDevice(device));
+  HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  const StaticTables& st = GetStaticTables();
+  std::vector<float> all;
+  for (int i = 0; i < 6; i++) all.insert(all.end(), st.basis[i].begin(), st.basis[i].end());
+  HIP_OK(hipMalloc(&d_basis_all, all.size() * 4));
+  HIP_OK(hipMemcpy(d_basis_all, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  std::vector<float> small;
+  for (int c = 1; c <= 32; c *= 2)
+    for (int k = 0; k < c; k++)
+      for (int nn = 0; nn < c; nn++) small.push_back((float)((k ? std::sqrt(2.0) : 1.0) * std::cos((2 * nn + 1) * k * M_PI / (2.0 * c))));
+  HIP_OK(hipMalloc(&d_basis_small, small.size() * 4));
+  HIP_OK(hipMemcpy(d_basis_small, small.data(), small.size() * 4, hipMemcpyHostToDevice));
+  HIP_OK(hipMalloc(&d_llf_scale, st.llf_scale.size() * 4));
+  HIP_OK(hipMemcpy(d_llf_scale, st.llf_scale.data(), st.llf_scale.size() * 4, hipMemcpyHostToDevice));
+  for (int o = 0; o < kNumOrders; o++) {
+    HIP_OK(hipMalloc(&d_natural[o], st.natural_order[o].size() * 2));
+    HIP_OK(hipMemcpy(d_natural[o], st.natural_order[o].data(), st.natural_order[o].size() * 2, hipMemcpyHostToDevice));
+  }
+  for (int q = 0; q < kNumQuantTables; q++) {
+    HIP_OK(hipMalloc(&d_dq[q], st.dq[q].size() * 4));
+    HIP_OK(hipMemcpy(d_dq[q], st.dq[q].data(), st.dq[q].size() * 4, hipMemcpyHostToDevice));
+    dq_n[q] = (uint32_t)(st.dq[q].size() / 3);
+  }
+  if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
+}
+
+JxlHipDecoder::~JxlHipDecoder() {
+  hipSetDevice(device);
+  if (pending) hipStreamSynchronize(last_stream);
+  for (auto e : events) hipEventDestroy(e);
+  hipFree(d_basis_all); hipFree(d_basis_small); hipFree(d_llf_scale);
+  for (auto p : d_natural) hipFree(p);
+  for (auto p : d_dq) hipFree(p);
+  hipFree(d_ws); hipFree(d_blob);
+  if (h_blob) hipHostFree(h_blob);
+  if (h_status) hipHostFree(h_status);
+  if (own_stream) hipStreamDestroy(own_stream);
+}
+
+void JxlHipDecoder::EnsureWs(size_t bytes) {
+  if (bytes <= ws_cap) return;
+  if (d_ws) HIP_OK(hipFree(d_ws));
+  d_ws = nullptr;
+  ws_cap = 0;
+  size_t cap = bytes + bytes / 8;
+  HIP_OK(hipMalloc(&d_ws, cap));
+  ws_cap = cap;
+}
+
+void JxlHipDecoder::EnsureBlob(size_t bytes) {
+  if (bytes > blob_cap) {
+    if (d_blob) HIP_OK(hipFree(d_blob));
+    d_blob = nullptr;
+    blob_cap = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIP_OK(hipMalloc(&d_blob, cap));
+    blob_cap = cap;
+  }
+  if (bytes > h_blob_cap) {
+    if (h_blob) HIP_OK(hipHostFree(h_blob));
+    h_blob = nullptr;
+    h_blob_cap = 0;
+    size_t cap = bytes + bytes / 4 + 4096;
+    HIP_OK(hipHostMalloc(&h_blob, cap, hipHostMallocDefault));
+    h_blob_cap = cap;
+  }
+}
+
+void JxlHipDecoder::Mark(const char* name, hipStream_t s) {
+  size_t i = stage_names.size();
+  stage_names.push_back(name);
+  if (events.size() <= i) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    events.push_back(e);
+  }
+  HIP_OK(hipEventRecord(events[i], s));
+}
+
+void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const size_t* sizes, const uint8_t* const* dev_data,
+                           uint8_t* const* dev_out, hipStream_t stream, bool sync, DecoderStatus* statuses, ErrorInfo* err) {
+  HIP_OK(hipSetDevice(device));
+  if (pending) { HIP_OK(hipStreamSynchronize(last_stream)); pending = false; }
+  if (!stream) stream = own_stream;
+  n = n_;
+  frames.assign(n, ParsedFrame());
+  parse_status.assign(n, DecoderStatus_Ok);
+  parse_msg.assign(n, "");
+  // ---- 1. host parse (threaded across images)
+  {
+    int nt = std::min<int>(n, std::max(1u, std::min(16u, std::thread::hardware_concurrency())));
+    std::vector<std::thread> th;
+    std::atomic<int> next(0);
+    auto work = [&]() {
+      for (;;) {
+        int i = next.fetch_add(1);
+        if (i >= n) return;
+        try {
+          ParseFile(host_data[i], sizes[i], false, frames[i]);
+        } catch (const ParseError& e) {
+          parse_status[i] = e.status;
+          parse_msg[i] = e.what();
+        } catch (const std::bad_alloc&) {
+          parse_status[i] = DecoderStatus_OutOfMemory;
+        } catch (const std::exception& e) {
+          parse_status[i] = DecoderStatus_DecodeError;
+          parse_msg[i] = e.what();
+        }
+      }
+    };
+    if (nt <= 1) work();
+    else {
+      for (int t = 0; t < nt; t++) th.emplace_back(work);
+      for (auto& t : th) t.join();
+    }
+  }
+  // images that failed to parse are skipped on the device (their DevImage stays zeroed, ng = 0)
+  // ---- 2. layout of blob and workspace
+  Bump blob, ws_zero, ws;
+  const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)n);
+  struct PerImg {
+    size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
+    size_t z_cellinfo, z_status, z_coef[3];
+    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, tmp[3], xyb[3], xyb2[3], inv_sigma, alpha;
+  };
+  std::vector<PerImg> L(n);
+  int total_lf = 0, total_groups = 0;
+  for (int i = 0; i < n; i++) {
+    if (parse_status[i] != DecoderStatus_Ok) continue;
+    const ParsedFrame& f = frames[i];
+    PerImg& l = L[i];
+    const size_t cells = (size_t)f.w8 * f.h8, pix = cells * 64, tiles = (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8);
+    l.sec_off = blob.Take(8 * f.sec_off.size());
+    l.sec_size = blob.Take(4 * f.sec_size.size());
+    l.tree = blob.Take(sizeof(DevTreeNode) * f.tree.size());
+    l.m_cmap = blob.Take(f.mcode.ctx_map.size());
+    l.m_cfg = blob.Take(4 * f.mcode.cfg.size());
+    l.m_alias = blob.Take(8 * f.mcode.alias.size());
+    l.a_cmap = blob.Take(f.acode.ctx_map.size());
+    l.a_cfg = blob.Take(4 * f.acode.cfg.size());
+    l.a_alias = blob.Take(8 * f.acode.alias.size());
+    for (int o = 0; o < kNumOrders; o++)
+      for (int c = 0; c < 3; c++) l.order[o][c] = f.custom_order[o][c].empty() ? 0 : blob.Take(2 * f.custom_order[o][c].size());
+    const bool resident = dev_data && dev_data[i] && f.cs_contiguous;
+    l.cs = resident ? 0 : blob.Take(f.cs_size + 16);
+    l.z_cellinfo = ws_zero.Take(4 * cells);
+    l.z_status = ws_zero.Take(64);
+    for (int c = 0; c < 3; c++) l.z_coef[c] = ws_zero.Take(4 * pix);
+    for (int c = 0; c < 3; c++) { l.lf[c] = ws.Take(4 * cells); l.lf_tmp[c] = ws.Take(4 * cells); l.lfq[c] = ws.Take(4 * cells); }
+    l.lf_extra = ws.Take(f.nlf);
+    l.rawq = ws.Take(2 * cells);
+    l.sharp = ws.Take(cells);
+    l.ytox = ws.Take(tiles);
+    l.ytob = ws.Take(tiles);
+    l.binfo = ws.Take((size_t)f.nlf * kBinfoInts * 4);
+    l.nzmap = ws.Take((size_t)f.ng * 3072);
+    for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); l.xyb2[c] = ws.Take(4 * pix); }
+    l.inv_sigma = ws.Take(4 * cells);
+    l.alpha = ws.Take((size_t)f.xsize * f.ysize);
+    total_lf += f.nlf;
+    total_groups += f.ng;
+  }
+  // lane mapping of the pass-group kernel
+  int lane_stride = 64;
+  if (lane_stride_override > 0) lane_stride = lane_stride_override;
+  else {
+    int waves_wanted = total_groups;     // at stride 64
+    while (lane_stride > 1 && waves_wanted > 4096) { lane_stride >>= 1; waves_wanted >>= 1; }
+  }
+  const int per_wg = 256 / lane_stride;
+  int n_pass_wg = 0;
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
+  const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
+  const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
+  const size_t zero_bytes = Align(ws_zero.off, 256);
+  EnsureBlob(blob.off);
+  EnsureWs(zero_bytes + ws.off);
+  if ((size_t)n * 16 > h_status_cap) {
+    if (h_status) HIP_OK(hipHostFree(h_status));
+    h_status = nullptr;
+    HIP_OK(hipHostMalloc(&h_status, (size_t)n * 16 * 4 + 64, hipHostMallocDefault));
+    h_status_cap = (size_t)n * 16;
+  }
+  // ---- 3. fill the pinned blob
+  memset(h_blob, 0, blob.off);
+  imgs.assign(n, DevImage());
+  status_off.assign(n, 0);
+  size_t lds_bytes = 0;
+  bool lds_ok = true, any_gab = false, any_alpha = false;
+  int max_epf = 0;
+  size_t max_cells = 1, max_pix = 1, max_padded = 8;
+  SectionTask* lf_tasks = (SectionTask*)(h_blob + off_lf_tasks);
+  SectionTask* pass_tasks = (SectionTask*)(h_blob + off_pass_tasks);
+  int nlf_t = 0, npass_t = 0;
+  uint8_t* wz = d_ws;
+  uint8_t* wr = d_ws + zero_bytes;
+  for (int i = 0; i < n; i++) {
+    memset(&imgs[i], 0, sizeof(DevImage));
+    if (parse_status[i] != DecoderStatus_Ok) continue;
+    const ParsedFrame& f = frames[i];
+    const PerImg& l = L[i];
+    DevImage& d = imgs[i];
+    d.w = f.xsize; d.h = f.ysize; d.w8 = f.w8; d.h8 = f.h8; d.wp = f.w8 * 8; d.hp = f.h8 * 8;
+    d.wt = (f.w8 + 7) / 8; d.ht = (f.h8 + 7) / 8;
+    d.xg = f.xg; d.yg = f.yg; d.ng = f.ng; d.xlf = f.xlf; d.ylf = f.ylf; d.nlf = f.nlf;
+    d.ncolor = f.ncolor; d.has_alpha = f.alpha_index >= 0; d.nch_out = d.ncolor + d.has_alpha;
+    d.to_srgb = f.color.all_default || (!f.color.have_gamma && f.color.tf == 13);
+    auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h_blob + off, src, bytes); };
+    put(l.sec_off, f.sec_off.data(), 8 * f.sec_off.size());
+    put(l.sec_size, f.sec_size.data(), 4 * f.sec_size.size());
+    put(l.tree, f.tree.data(), sizeof(DevTreeNode) * f.tree.size());
+    auto code = [&](const HostCode& hc, size_t cm, size_t cf, size_t al, DevCode& dc) {
+      put(cm, hc.ctx_map.data(), hc.ctx_map.size());
+      std::vector<uint32_t> cfgp(hc.cfg.size());
+      for (size_t k = 0; k < hc.cfg.size(); k++) cfgp[k] = hc.cfg[k].split | hc.cfg[k].msb << 8 | hc.cfg[k].lsb << 16;
+      put(cf, cfgp.data(), 4 * cfgp.size());
+      put(al, hc.alias.data(), 8 * hc.alias.size());
+      dc.ctx_map = d_blob + cm;
+      dc.cfg = (const uint32_t*)(d_blob + cf);
+      dc.alias = (const uint64_t*)(d_blob + al);
+      dc.num_ctx = (uint32_t)hc.ctx_map.size();
+      dc.num_clusters = hc.num_hist;
+      dc.log_alpha = hc.log_alpha;
+    };
+    code(f.mcode, l.m_cmap, l.m_cfg, l.m_alias, d.mcode);
+    code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
+    d.sec_off = (const uint64_t*)(d_blob + l.sec_off);
+    d.sec_size = (const uint32_t*)(d_blob + l.sec_size);
+    d.tree = (const DevTreeNode*)(d_blob + l.tree);
+    d.tree_size = (int32_t)f.tree.size();
+    const bool resident = dev_data && dev_data[i] && f.cs_contiguous;
+    if (resident) d.cs = dev_data[i] + f.cs_file_offset;
+    else { put(l.cs, f.cs, f.cs_size); d.cs = d_blob + l.cs; }
+    d.cs_size = f.cs_size;
+    d.num_presets = f.num_presets;
+    d.num_block_ctx = f.num_block_ctx;
+    memcpy(d.block_ctx_map, f.block_ctx_map.data(), std::min(sizeof(d.block_ctx_map), f.block_ctx_map.size()));
+    d.n_qf = (int32_t)f.qf_thr.size();
+    for (size_t k = 0; k < f.qf_thr.size() && k < 15; k++) d.qf_thr[k] = f.qf_thr[k];
+    for (int o = 0; o < kNumOrders; o++)
+      for (int c = 0; c < 3; c++) {
+        if (f.custom_order[o][c].empty()) d.order[o * 3 + c] = d_natural[o];
+        else { put(l.order[o][c], f.custom_order[o][c].data(), 2 * f.custom_order[o][c].size()); d.order[o * 3 + c] = (const uint16_t*)(d_blob + l.order[o][c]); }
+      }
+    d.inv_global_scale = 65536.0f / f.global_scale;
+    d.quant_scale = f.global_scale / 65536.0f;
+    for (int c = 0; c < 3; c++) d.mul_lf[c] = f.m_lf[c] * (d.inv_global_scale / f.quant_lf);
+    d.inv_color_factor = 1.0f / f.color_factor;
+    d.lf_cfl_x = f.base_x + f.ytox_lf * d.inv_color_factor;
+    d.lf_cfl_b = f.base_b + f.ytob_lf * d.inv_color_factor;
+    d.base_x = f.base_x; d.base_b = f.base_b;
+    d.x_dm = std::pow(0.8f, (float)f.x_qm_scale - 2.0f);
+    d.b_dm = std::pow(0.8f, (float)f.b_qm_scale - 2.0f);
+    memcpy(d.qbias, f.qbias, sizeof(d.qbias));
+    for (int q = 0; q < kNumQuantTables; q++) { d.dq[q] = d_dq[q]; d.dq_n[q] = dq_n[q]; }
+    d.gab = f.gab; d.epf_iters = f.epf_iters; d.skip_lf_smoothing = (f.flags & 128) ? 1 : 0;
+    for (int c = 0; c < 3; c++) {
+      float div = 1.0f + 4.0f * (f.gab_w1[c] + f.gab_w2[c]);
+      d.gab_w[c][0] = 1.0f / div; d.gab_w[c][1] = f.gab_w1[c] / div; d.gab_w[c][2] = f.gab_w2[c] / div;
+    }
+    memcpy(d.epf_sharp_lut, f.epf_sharp_lut, sizeof(d.epf_sharp_lut));
+    memcpy(d.epf_channel_scale, f.epf_channel_scale, sizeof(d.epf_channel_scale));
+    d.epf_quant_mul = f.epf_quant_mul; d.epf_pass0_sigma_scale = f.epf_pass0_sigma_scale;
+    d.epf_pass2_sigma_scale = f.epf_pass2_sigma_scale; d.epf_border_sad_mul = f.epf_border_sad_mul;
+    for (int k = 0; k < 9; k++) d.opsin_inv[k] = f.opsin_inv[k] * (255.0f / f.intensity_target);
+    for (int k = 0; k < 3; k++) { d.opsin_bias[k] = f.opsin_bias[k]; d.opsin_bias_cbrt[k] = std::cbrt(f.opsin_bias[k]); }
+    // planes
+    d.cellinfo = (uint32_t*)(wz + l.z_cellinfo);
+    d.status = (uint32_t*)(wz + l.z_status);
+    status_off[i] = l.z_status;
+    for (int c = 0; c < 3; c++) {
+      d.coef[c] = (int32_t*)(wz + l.z_coef[c]);
+      d.lf[c] = (float*)(wr + l.lf[c]); d.lf_tmp[c] = (float*)(wr + l.lf_tmp[c]); d.lfq[c] = (int32_t*)(wr + l.lfq[c]);
+      d.lf_final[c] = d.skip_lf_smoothing ? d.lf[c] : d.lf_tmp[c];
+      d.tmp[c] = (float*)(wr + l.tmp[c]); d.xyb[c] = (float*)(wr + l.xyb[c]); d.xyb2[c] = (float*)(wr + l.xyb2[c]);
+    }
+    d.lf_extra = wr + l.lf_extra;
+    d.rawq = (uint16_t*)(wr + l.rawq); d.sharp = wr + l.sharp;
+    d.ytox = (int8_t*)(wr + l.ytox); d.ytob = (int8_t*)(wr + l.ytob);
+    d.binfo = (int32_t*)(wr + l.binfo); d.nzmap = wr + l.nzmap;
+    d.alpha32 = (int32_t*)d.tmp[0];
+    d.inv_sigma = (float*)(wr + l.inv_sigma);
+    d.alpha = wr + l.alpha;
+    d.out = dev_out[i];
+    // stage routing (ping-pong between xyb and xyb2)
+    float** cur = d.xyb;
+    float** other = d.xyb2;
+    d.stage_on[0] = f.gab ? 1 : 0;
+    d.stage_on[1] = f.epf_iters == 3;
+    d.stage_on[2] = f.epf_iters >= 1;
+    d.stage_on[3] = f.epf_iters >= 2;
+    d.stage_on[4] = 1;
+    for (int s = 0; s < 5; s++) {
+      for (int c = 0; c < 3; c++) { d.stage_in[s][c] = cur[c]; d.stage_out[s][c] = other[c]; }
+      if (s < 4 && d.stage_on[s]) std::swap(cur, other);
+    }
+    any_gab |= f.gab;
+    any_alpha |= d.has_alpha != 0;
+    max_epf = std::max<int>(max_epf, f.epf_iters);
+    max_cells = std::max(max_cells, (size_t)f.w8 * f.h8);
+    max_pix = std::max(max_pix, (size_t)f.xsize * f.ysize);
+    max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
+    // LDS budget of the pass-group kernel
+    size_t lds = 8 * (f.acode.alias.size() + f.mcode.alias.size());
+    lds = Align(lds, 16) + sizeof(DevTreeNode) * f.tree.size() + 4 * (f.acode.cfg.size() + f.mcode.cfg.size()) +
+          f.acode.ctx_map.size() + f.mcode.ctx_map.size() + 64;
+    if (lds > 64 * 1024) lds_ok = false;
+    lds_bytes = std::max(lds_bytes, lds);
+    for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
+    for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
+  }
+  memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
+  d_imgs = (DevImage*)(d_blob + off_imgs);
+  // ---- 4. enqueue
+  stage_names.clear();
+  Mark("start", stream);
+  HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, stream));
+  HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, stream));
+  Mark("upload+clear", stream);
+  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, stream);
+  Mark("lf_groups", stream);
+  LaunchLfPixelStages(d_imgs, n, max_cells, stream);
+  Mark("lf_pixels", stream);
+  LaunchPassGroups(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_ok ? lds_bytes : 0, stream);
+  Mark("pass_groups", stream);
+  if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
+  if (any_alpha) LaunchAlphaToU8(d_imgs, n, max_pix, stream);
+  LaunchReconstruct(d_imgs, n, max_padded, max_cells, d_basis_all, d_basis_small, d_llf_scale, stream);
+  Mark("reconstruct", stream);
+  if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
+  LaunchFiltersAndOutput(d_imgs, n, max_pix, any_gab, max_epf, stream);
+  Mark("filters+output", stream);
+  HIP_OK(hipGetLastError());
+  last_stream = stream;
+  pending = true;
+  if (sync) {
+    DecoderStatus st = Finish(statuses, err);
+    (void)st;
+    if (debug_taps) CopyPlaneTap(2);
+  } else if (statuses) {
+    for (int i = 0; i < n; i++) statuses[i] = parse_status[i];
+  }
+}
+
+void JxlHipDecoder::CopyPlaneTap(int stage) {
+  for (int i = 0; i < n; i++) {
+    if (parse_status[i] != DecoderStatus_Ok) continue;
+    const DevImage& d = imgs[i];
+    size_t bytes = (size_t)d.wp * d.hp * 4;
+    for (int c = 0; c < 3; c++) {
+      std::vector<uint8_t>& dst = stage == 0 ? taps[i].qcoef[c] : (stage == 1 ? taps[i].xyb_idct[c] : taps[i].xyb_filtered[c]);
+      const void* src = stage == 0 ? (const void*)d.coef[c] : (stage == 1 ? (const void*)d.xyb[c] : (const void*)d.stage_in[4][c]);
+      dst.resize(bytes);
+      HIP_OK(hipMemcpy(dst.data(), src, bytes, hipMemcpyDeviceToHost));
+    }
+  }
+}
+
+DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
+  HIP_OK(hipSetDevice(device));
+  if (!pending) return DecoderStatus_Ok;
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok)
+      HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, last_stream));
+  HIP_OK(hipStreamSynchronize(last_stream));
+  pending = false;
+  stage_ms.assign(stage_names.size(), 0.f);
+  for (size_t i = 1; i < stage_names.size(); i++) hipEventElapsedTime(&stage_ms[i], events[i - 1], events[i]);
+  DecoderStatus worst = DecoderStatus_Ok;
+  for (int i = 0; i < n; i++) {
+    DecoderStatus st = parse_status[i];
+    if (st != DecoderStatus_Ok) {
+      if (worst == DecoderStatus_Ok) SetErr(err, "%s", parse_msg[i].c_str());
+    } else if (h_status[(size_t)i * 16]) {
+      uint32_t bits = h_status[(size_t)i * 16];
+      st = DecoderStatus_DecodeError;
+      if (worst == DecoderStatus_Ok)
+        SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
+               bits & kErrUnsupportedHeader ? " unsupported-modular-header" : "", bits & kErrUnsupportedTree ? " unsupported-tree" : "",
+               bits & kErrBlockLayout ? " invalid-varblock-layout" : "", bits & kErrRange ? " value-out-of-range" : "");
+    }
+    if (statuses) statuses[i] = st;
+    if (st != DecoderStatus_Ok && worst == DecoderStatus_Ok) worst = st;
+  }
+  return worst;
+}
+
+// ====================================================================== C-ABI
+extern "C" {
+
+uint32_t GetLibJxlVersion(void) {
+  // This library is not libjxl; it reports the libjxl API level whose behaviour it follows (0.11.1).
+  return (0u << 24) | (11u << 16) | (1u << 8);
+}
+
+JxlHipDecoder* jxlhip_decoder_create(int32_t device, ErrorInfo* err) {
+  try {
+    return new JxlHipDecoder(device);
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    return nullptr;
+  }
+}
+
+void jxlhip_decoder_destroy(JxlHipDecoder* dec) { delete dec; }
+
+DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, JxlHipImageInfo* info, ErrorInfo* err) {
+  if (!data || !info) return DecoderStatus_NullParameter;
+  try {
+    ParsedFrame f;
+    ParseFile(data, size, true, f);
+    info->width = f.xsize; info->height = f.ysize;
+    info->has_alpha = f.alpha_index >= 0;
+    info->num_channels = f.ncolor + info->has_alpha;
+    info->xsize_blocks = f.w8; info->ysize_blocks = f.h8;
+    info->num_groups = f.ng; info->num_lf_groups = f.nlf;
+    info->epf_iters = f.epf_iters; info->gaborish = f.gab;
+    info->codestream_bytes = f.cs_size;
+    return DecoderStatus_Ok;
+  } catch (const ParseError& e) {
+    SetErr(err, "%s", e.what());
+    return e.status;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    return DecoderStatus_DecodeError;
+  }
+}
+
+DecoderStatus jxlhip_decode_batch(JxlHipDecoder* dec, int32_t n, const uint8_t* const* host_data, const size_t* sizes,
+                                  const uint8_t* const* dev_data, uint8_t* const* dev_out, void* stream, int32_t synchronize,
+                                  DecoderStatus* statuses, ErrorInfo* err) {
+  if (!dec || !host_data || !sizes || !dev_out || n <= 0) return DecoderStatus_NullParameter;
+  try {
+    dec->Decode(n, host_data, sizes, dev_data, dev_out, (hipStream_t)stream, synchronize != 0, statuses, err);
+    if (statuses) for (int i = 0; i < n; i++) if (statuses[i] != DecoderStatus_Ok) return statuses[i];
+    return DecoderStatus_Ok;
+  } catch (const std::bad_alloc&) {
+    return DecoderStatus_OutOfMemory;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    return DecoderStatus_DecodeError;
+  }
+}
+
+DecoderStatus jxlhip_finish(JxlHipDecoder* dec, DecoderStatus* statuses, ErrorInfo* err) {
+  if (!dec) return DecoderStatus_NullParameter;
+  try {
+    return dec->Finish(statuses, err);
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    return DecoderStatus_DecodeError;
+  }
+}
+
+int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
+  if (!dec || !name) return 0;
+  if (!strcmp(name, "debug_taps")) { dec->debug_taps = value != 0; return 1; }
+  if (!strcmp(name, "lane_stride")) { dec->lane_stride_override = value; return 1; }
+  return 0;
+}
+
+size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, const char* name, int32_t channel, void* dst, size_t capacity) {
+  if (!dec || index < 0 || index >= dec->n || !name || dec->pending) return 0;
+  if (dec->parse_status[index] != DecoderStatus_Ok) return 0;
+  const DevImage& d = dec->imgs[index];
+  std::string nm(name);
+  const size_t cells = (size_t)d.w8 * d.h8, pix = (size_t)d.wp * d.hp;
+  const void* src = nullptr;
+  size_t bytes = 0;
+  bool host = false;
+  const int c = std::min(2, std::max(0, channel));
+  if (nm == "lf") { src = d.lf_final[c]; bytes = cells * 4; }
+  else if (nm == "lf_quant") { src = d.lfq[c]; bytes = cells * 4; }
+  else if (nm == "cellinfo") { src = d.cellinfo; bytes = cells * 4; }
+  else if (nm == "raw_quant") { src = d.rawq; bytes = cells * 2; }
+  else if (nm == "sharpness") { src = d.sharp; bytes = cells; }
+  else if (nm == "ytox") { src = d.ytox; bytes = (size_t)d.wt * d.ht; }
+  else if (nm == "ytob") { src = d.ytob; bytes = (size_t)d.wt * d.ht; }
+  else if (nm == "alpha") { src = d.alpha; bytes = (size_t)d.w * d.h; }
+  else if (nm == "inv_sigma") { src = d.inv_sigma; bytes = cells * 4; }
+  else if (dec->debug_taps && (size_t)index < dec->taps.size()) {
+    host = true;
+    if (nm == "qcoef") { src = dec->taps[index].qcoef[c].data(); bytes = dec->taps[index].qcoef[c].size(); }
+    else if (nm == "xyb_idct") { src = dec->taps[index].xyb_idct[c].data(); bytes = dec->taps[index].xyb_idct[c].size(); }
+    else if (nm == "xyb_filtered") { src = dec->taps[index].xyb_filtered[c].data(); bytes = dec->taps[index].xyb_filtered[c].size(); }
+  }
+  (void)pix;
+  if (!src || !bytes) return 0;
+  if (dst && capacity) {
+    size_t nb = std::min(bytes, capacity);
+    if (host) memcpy(dst, src, nb);
+    else if (hipMemcpy(dst, src, nb, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  }
+  return bytes;
+}
+
+int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity) {
+  if (!dec) return 0;
+  int32_t k = 0;
+  for (size_t i = 1; i < dec->stage_names.size() && i < dec->stage_ms.size() && k < capacity; i++, k++) {
+    if (names) names[k] = dec->stage_names[i].c_str();
+    if (ms) ms[k] = dec->stage_ms[i];
+  }
+  return k;
+}
+
+// ---------------------------------------------------------------------- LoadImage
+static JxlHipDecoder* ThreadDecoder() {
+  static thread_local std::unique_ptr<JxlHipDecoder> dec;
+  if (!dec) dec.reset(new JxlHipDecoder(-1));
+  return dec.get();
+}
+
+DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, ErrorInfo* err) {
+  if (!cb || !data) return DecoderStatus_NullParameter;   // Decoder/JxlDecoder.cpp:802-805
+  uint8_t* d_out = nullptr;
+  uint8_t* h_out = nullptr;
+  DecoderStatus result = DecoderStatus_Ok;
+  try {
+    // ---- pass 1: basic info, colour profile, metadata boxes (Decoder/JxlDecoder.cpp:412-793)
+    ParsedFrame f;
+    ParseFile(data, size, true, f);
+    if (f.xsize > 0x7FFFFFFFu || f.ysize > 0x7FFFFFFFu) return DecoderStatus_ImageDimensionExceedsInt32;   // :477-481
+    int black = 0, alphas = 0;
+    for (auto& e : f.ec) { if (e.type == 4) black++; if (e.type == 0) alphas++; }
+    if ((f.ncolor != 1 && f.ncolor != 3) || black > 1 || alphas > 1) return DecoderStatus_UnsupportedChannelFormat;   // :485-490
+    const bool has_alpha = f.alpha_index >= 0;
+    if (black) { SetErr(err, "CMYK images are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
+    if (f.exp_bits > 0 || f.bits > 8) { SetErr(err, "Only 8-bit integer images are supported on the GPU path yet (got %u bits).", f.bits); return DecoderStatus_DecodeError; }
+    cb->setBasicInfo((int32_t)f.xsize, (int32_t)f.ysize, f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb,
+                     ImageChannelRepresentation_Uint8, has_alpha);   // :558
+    // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108)
+    {
+      const ColorInfo& c = f.color;
+      int prof = -1;
+      const uint32_t tf = c.all_default ? 13 : c.tf, wp = c.all_default ? 1 : c.white_point, pr = c.all_default ? 1 : c.primaries;
+      if (!c.have_gamma && wp == 1) {
+        if (f.ncolor == 3) {
+          if (tf == 8 && pr == 1) prof = KnownColorProfile_LinearSrgb;
+          else if (tf == 13 && pr == 1) prof = KnownColorProfile_Srgb;
+        } else {
+          if (tf == 8) prof = KnownColorProfile_LinearGray;
+          else if (tf == 13) prof = KnownColorProfile_GraySrgbTRC;
+        }
+      }
+      if (prof < 0) { SetErr(err, "Colour encoding is not supported on the GPU path yet (only sRGB / linear sRGB / gray)."); return DecoderStatus_DecodeError; }
+      if (!cb->setKnownColorProfile((KnownColorProfile)prof)) return DecoderStatus_CreateMetadataError;   // :648-651
+    }
+    if (f.exif && f.exif_size && !cb->setExif(const_cast<uint8_t*>(f.exif), f.exif_size)) return DecoderStatus_CreateMetadataError;   // :764
+    for (auto& x : f.xml)
+      if (!cb->setXmp(const_cast<uint8_t*>(x.first), x.second)) return DecoderStatus_CreateMetadataError;   // :775-782
+    // ---- pass 2: the frame (Decoder/JxlDecoder.cpp:217-410)
+    JxlHipDecoder* dec = ThreadDecoder();
+    const int nch = f.ncolor + (has_alpha ? 1 : 0);
+    const size_t bytes = (size_t)f.xsize * f.ysize * nch;   // tightly packed, :291-313
+    HIP_OK(hipMalloc(&d_out, bytes));
+    HIP_OK(hipHostMalloc(&h_out, bytes, hipHostMallocDefault));
+    DecoderStatus st = DecoderStatus_Ok;
+    const uint8_t* hd = data;
+    uint8_t* od = d_out;
+    dec->Decode(1, &hd, &size, nullptr, &od, nullptr, true, &st, err);
+    if (st != DecoderStatus_Ok) result = st;
+    else {
+      HIP_OK(hipMemcpy(h_out, d_out, bytes, hipMemcpyDeviceToHost));
+      std::vector<char> name;
+      if (!f.name.empty()) { name.assign(f.name.begin(), f.name.end()); name.push_back(0); }   // nameLength includes the NUL (:274,369)
+      if (!cb->setLayerData(h_out, name.empty() ? nullptr : name.data(), name.size())) result = DecoderStatus_CreateLayerError;   // :384-395
+    }
+  } catch (const ParseError& e) {
+    SetErr(err, "%s", e.what());
+    result = e.status;
+  } catch (const std::bad_alloc&) {
+    result = DecoderStatus_OutOfMemory;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    result = DecoderStatus_DecodeError;
+  } catch (...) {
+    result = DecoderStatus_DecodeError;
+  }
+  if (d_out) hipFree(d_out);
+  if (h_out) hipHostFree(h_out);
+  return result;
+}
+
+EncoderStatus SaveImage(const BitmapData* bitmap, const EncoderOptions* options, const EncoderImageMetadata* metadata,
+                        IOCallbacks* callbacks, ErrorInfo* err, ProgressProc progress) {
+  if (!bitmap || !options || !callbacks || !metadata) return EncoderStatus_NullParameter;   // Encoder/JxlEncoder.cpp:155-158
+  if (progress && !progress(0)) return EncoderStatus_UserCanceled;                           // :162
+  SetErr(err, "SaveImage: the MI355X encode path is not built yet (decode path only in this round).");
+  return EncoderStatus_EncodeError;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------- host-only introspection (CPU tests)
+extern "C" {
+
+// Full host-side parse (no GPU): returns the status and a few facts about the parsed tables.
+// facts[0..7] = tree nodes, modular clusters, modular log_alpha, AC clusters, AC log_alpha, AC contexts, presets, sections
+JXLFILETYPEIO_API DecoderStatus jxlhip_parse_check(const uint8_t* data, size_t size, int32_t* facts, ErrorInfo* err) {
+  if (!data) return DecoderStatus_NullParameter;
+  try {
+    ParsedFrame f;
+    ParseFile(data, size, false, f);
+    if (facts) {
+      facts[0] = (int32_t)f.tree.size(); facts[1] = f.mcode.num_hist; facts[2] = f.mcode.log_alpha;
+      facts[3] = f.acode.num_hist; facts[4] = f.acode.log_alpha; facts[5] = (int32_t)f.acode.ctx_map.size();
+      facts[6] = f.num_presets; facts[7] = (int32_t)f.sec_off.size();
+    }
+    return DecoderStatus_Ok;
+  } catch (const ParseError& e) {
+    SetErr(err, "%s", e.what());
+    return e.status;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    return DecoderStatus_DecodeError;
+  }
+}
+
+// name: "natural_order" (index = order bucket, uint16), "dequant" (index = quant table, float, 3*n),
+//       "basis" (index = log2(N/8), float N*N).  Returns the byte size.
+JXLFILETYPEIO_API size_t jxlhip_static_table(const char* name, int32_t index, void* dst, size_t capacity) {
+  const StaticTables& st = GetStaticTables();
+  const void* src = nullptr;
+  size_t bytes = 0;
+  std::string nm(name ? name : "");
+  if (nm == "natural_order" && index >= 0 && index < kNumOrders) { src = st.natural_order[index].data(); bytes = st.natural_order[index].size() * 2; }
+  else if (nm == "dequant" && index >= 0 && index < kNumQuantTables) { src = st.dq[index].data(); bytes = st.dq[index].size() * 4; }
+  else if (nm == "basis" && index >= 0 && index < 6) { src = st.basis[index].data(); bytes = st.basis[index].size() * 4; }
+  if (src && dst) memcpy(dst, src, std::min(bytes, capacity));
+  return bytes;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+// Structures shared between the host-side frame parser and the HIP kernels.
+// Everything a kernel needs about one image lives in a DevImage record in HBM; batches are
+// arrays of DevImage and every kernel takes (images, task table) so that one launch covers
+// all images of a batch.
+#pragma once
+#include <stdint.h>
+
+namespace jxlhip {
+
+constexpr int kNumStrategies = 27;
+constexpr int kNumOrders = 13;
+constexpr int kNumQuantTables = 17;
+constexpr int kGroupDim = 256;
+constexpr int kGroupBlocks = 32;        // 8x8 cells per group side
+constexpr int kLfGroupBlocks = 256;     // 8x8 cells per LF group side
+constexpr int kMaxClustersLds = 128;
+
+// error bits written by kernels into DevImage::status[0]
+enum DevError : uint32_t {
+  kErrNone = 0,
+  kErrBitstream = 1u << 0,        // overrun / invalid symbol / final ANS state mismatch
+  kErrUnsupportedHeader = 1u << 1,  // modular group header other than {global tree, default wp, no transforms}
+  kErrUnsupportedTree = 1u << 2,    // weighted predictor / reference-channel properties on the GPU path
+  kErrBlockLayout = 1u << 3,        // invalid varblock placement
+  kErrRange = 1u << 4,              // value out of range (sharpness, quant, cfl)
+};
+
+struct DevTreeNode {    // 16 bytes
+  int32_t property;     // -1: leaf
+  int32_t splitval;     // leaf: offset
+  uint32_t a;           // inner: child for (property > splitval); leaf: predictor | ctx << 8
+  uint32_t b;           // inner: other child; leaf: multiplier
+};
+
+struct DevCode {
+  const uint8_t* ctx_map;
+  const uint32_t* cfg;      // per cluster: split_exponent | msb << 8 | lsb << 16
+  const uint64_t* alias;    // [cluster << log_alpha | i]: low32 = cutoff | right << 8 | freq0 << 16, high32 = offsets1 | (freq1^freq0) << 16
+  uint32_t num_ctx;
+  uint32_t num_clusters;
+  uint32_t log_alpha;
+  uint32_t pad;
+};
+
+struct DevImage {
+  // geometry
+  int32_t w, h, w8, h8, wp, hp, wt, ht;
+  int32_t xg, yg, ng, xlf, ylf, nlf;
+  int32_t ncolor, has_alpha, nch_out, to_srgb;
+  // codestream
+  const uint8_t* cs;
+  uint64_t cs_size;
+  const uint64_t* sec_off;   // logical section -> byte offset in cs
+  const uint32_t* sec_size;
+  // modular (global tree + code)
+  const DevTreeNode* tree;
+  int32_t tree_size;
+  int32_t pad0;
+  DevCode mcode;
+  // HF
+  DevCode acode;
+  int32_t num_presets, num_block_ctx;
+  uint8_t block_ctx_map[39 * 16];   // [(c'*13 + ord) * (nqf+1) + qf_idx]
+  uint32_t qf_thr[15];
+  int32_t n_qf;
+  const uint16_t* order[kNumOrders * 3];   // coefficient order per (bucket, channel)
+  // quantisation
+  float inv_global_scale, quant_scale;
+  float mul_lf[3];
+  float lf_cfl_x, lf_cfl_b;
+  float base_x, base_b, inv_color_factor;
+  float x_dm, b_dm;
+  float qbias[4];
+  const float* dq[kNumQuantTables];   // 3 * n floats each (1/weight), stored layout
+  uint32_t dq_n[kNumQuantTables];
+  // loop filters / colour
+  int32_t gab, epf_iters, skip_lf_smoothing, pad1;
+  float gab_w[3][3];        // [c][0..2] normalised centre, edge, corner
+  float epf_sharp_lut[8];
+  float epf_channel_scale[3];
+  float epf_quant_mul, epf_pass0_sigma_scale, epf_pass2_sigma_scale, epf_border_sad_mul;
+  float opsin_inv[9];
+  float opsin_bias[3], opsin_bias_cbrt[3];
+  // workspace planes (device)
+  float* lf[3];             // w8*h8, dequantised
+  float* lf_tmp[3];         // smoothing output
+  float* lf_final[3];       // what LLF reads (lf_tmp when smoothing is on)
+  uint8_t* lf_extra;        // per LF group: extra_precision
+  int32_t* lfq[3];          // quantised LF (X,Y,B)
+  uint32_t* cellinfo;       // per 8x8 cell: strategy | ix << 8 | iy << 13 | log2cx << 18 | log2cy << 21 | valid << 31
+  uint16_t* rawq;           // per cell
+  uint8_t* sharp;           // per cell
+  int8_t* ytox;             // per 64x64 tile
+  int8_t* ytob;
+  int32_t* binfo;           // scratch per LF group (kBinfoInts ints): cfl x, cfl b, block info rows, sharpness
+  uint8_t* nzmap;           // scratch per group: 3 * 1024 bytes (non-zero counts per 8x8 cell)
+  int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
+  int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
+  float* tmp[3];            // wp*hp
+  float* xyb[3];            // wp*hp
+  float* xyb2[3];           // wp*hp
+  float* inv_sigma;         // per cell
+  // loop-filter / output stage routing: 0 gaborish, 1 epf0, 2 epf1, 3 epf2, 4 output
+  float* stage_in[5][3];
+  float* stage_out[5][3];
+  int32_t stage_on[5];
+  int32_t pad2;
+  uint8_t* alpha;           // w*h
+  uint8_t* out;             // w*h*nch_out interleaved
+  uint32_t* status;         // [0] error bits, [1..] debug
+};
+
+constexpr int kBinfoInts = 2 * 1024 + 2 * 65536 + 65536;
+
+struct SectionTask {   // one workgroup's share of sections of one image
+  int32_t image;
+  int32_t first;   // first LF group / group index
+  int32_t count;   // sections handled by this workgroup
+  int32_t pad;
+};
+
+}  // namespace jxlhip

@@ -1,0 +1,16 @@
+// Launch wrappers of the HIP kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace jxlhip {
+
+void LaunchLfGroups(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
+void LaunchPassGroups(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
+void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
+void LaunchAlphaToU8(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
+void LaunchReconstruct(const DevImage* imgs, int nimg, size_t max_padded_pixels, size_t max_cells, const float* basis_all,
+                       const float* basis_small, const float* llf_scale, hipStream_t s);
+void LaunchFiltersAndOutput(const DevImage* imgs, int nimg, size_t max_pixels, bool any_gab, int max_epf, hipStream_t s);
+
+}  // namespace jxlhip

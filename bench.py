@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Benchmark of the JPEG XL decode hot path on MI355X (contract: README of the build driver).
+
+One *step* = one pass of the hot path over one batch: B copies of the 3840x2160 RGBA8 lossy VarDCT (distance 1.0)
+synthetic image (BASELINE.json configs[1]) decoded from HBM-resident .jxl bytes to HBM-resident RGBA8, through the
+C-ABI batch entry point jxlhip_decode_batch (host header parsing included in the timed region).
+value = megapixels decoded per second, whole job (all ranks).  With --gpus N each rank decodes its own batch
+(weak scaling; independent images shard with no data-path collective — DESIGN.md "Multi-GPU").
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (pass_group_kernel: HF-coefficient + alpha entropy decode), bound = HBM;
+                achieved = algorithmic bytes per launch (B * (jxl bytes + W*H*4)) / its HIP-event duration
+  cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FIXTURE = os.path.join(ROOT, "tests", "golden", "synth_3840x2160_seed2_d1.jxl")
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(data, width, height, seconds_budget=12.0):
+    """Times the CPU oracle on the same file (bounded sample).  Only this leg touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = os.cpu_count() or 1
+    threads = min(cores, 32)
+    O.decode(data, num_threads=threads)  # warm-up (page-in, table init)
+    times = []
+    t_end = time.perf_counter() + seconds_budget
+    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 8):
+        t0 = time.perf_counter()
+        O.decode(data, num_threads=threads)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(width * height / best / 1e6, 3), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": "%d decodes of the same 3840x2160 RGBA8 d=1.0 file with the CPU oracle (%d threads over groups), best of %d"
+                      % (len(times), threads, len(times)), "host_cores": cores, "libjxl": "unavailable (offline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "16")))
+    ap.add_argument("--lane-stride", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pdn_jpegxl_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    data = open(FIXTURE, "rb").read()
+    info = api.peek(data)
+    W, H, C = info.width, info.height, info.num_channels
+    B = args.batch
+    dec = api.Decoder(local_rank)
+    dec.set_option("lane_stride", args.lane_stride)
+    # inputs resident in HBM before the timed region (padded: the bit readers fetch whole 32-bit words)
+    src = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+    src[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    outs = [torch.empty(W * H * C, dtype=torch.uint8, device="cuda") for _ in range(B)]
+    files = [data] * B
+    dev_in = [src.data_ptr()] * B
+    dev_out = [o.data_ptr() for o in outs]
+
+    def step():
+        st = dec.decode_batch(files, dev_out, dev_in, synchronize=True)
+        assert all(s == 0 for s in st), st
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    stage_sum = {}
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in dec.stage_times().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # single-image latency (B = 1), outside the timed region
+    lat = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        dec.decode_batch([data], dev_out[:1], dev_in[:1], synchronize=True)
+        lat.append((time.perf_counter() - t1) * 1e3)
+    lat_stages = dec.stage_times()
+
+    if rank == 0:
+        mp = W * H / 1e6
+        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+        dom = "pass_groups"
+        dom_ms = stage_ms.get(dom, 0.0)
+        alg_bytes = B * (len(data) + W * H * C)
+        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        line = {
+            "metric": "megapixels/sec decode (4K lossy VarDCT)",
+            "value": round(world * B * args.steps * mp / elapsed, 2),
+            "unit": "MP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "3840x2160 RGBA8 lossy VarDCT (distance=1.0) decode, HBM-resident .jxl -> HBM RGBA8",
+                       "batch_per_gpu": B, "jxl_bytes": len(data), "groups_per_image": info.num_groups,
+                       "lane_stride": args.lane_stride or "auto", "parallelism": "images sharded across ranks, no data-path collective"},
+            "roofline": {"bound": "hbm", "kernel": "pass_group_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(dom_ms, 4)},
+            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "single_image": {"latency_ms": round(min(lat), 3), "mp_per_s": round(mp / (min(lat) * 1e-3), 2),
+                             "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(data, W, H)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,3 +119,7 @@ size_t jxo_dequant_table(int strategy, int c, float* dst, size_t capacity) {
   return dq.n[q];
 }
 }
+extern "C" {
+void jxo_idct_stored(int R, int C, const float* stored, float* out) { IdctStored(R, C, stored, out, C); }
+void jxo_dct_stored(int R, int C, const float* in, float* stored) { DctStored(R, C, in, C, stored); }
+}

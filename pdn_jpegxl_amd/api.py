@@ -79,6 +79,12 @@ def lib(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # When PyTorch is present it must load first: both link libamdhip64.so.7 and have to share ONE HIP runtime
+        # (torch bundles its own); loading the system runtime first leaves torch without a visible GPU.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = _build.lib_path()
     if not os.path.exists(path):
         if not build_if_missing:

@@ -1,0 +1,52 @@
+"""GPU tests of the drop-in boundary: LoadImage driven exactly like src/Interop/JpegXLNative.cs drives it."""
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_load_image_callback_order_and_pixels(oracle):
+    img = synth(512, 512, 1)  # BASELINE.json configs[0] shape
+    exif = b"\0\0\0\0II*\0" + bytes(range(64))
+    xmp = b"<x:xmpmeta xmlns:x='adobe:ns:meta/'/>"
+    data = oracle.encode(img, exif=exif, xmp=xmp)
+    got = api.load_image(data)
+    assert got.trace == ["setBasicInfo", "setKnownColorProfile", "setExif", "setXmp", "setLayerData"]
+    assert (got.width, got.height, got.format, got.has_transparency) == (512, 512, "Rgb", True)
+    assert got.channel_representation == 0 and got.known_profile == "Srgb"
+    assert got.exif == exif and got.xmp == xmp and got.layer_name is None
+    ref = oracle.decode(data).pixels
+    d = np.abs(got.pixels.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (got.pixels[..., 3] == img[..., 3]).all()
+
+
+def test_load_image_rgb_and_gray(oracle):
+    img = synth(300, 300, 2)
+    got = api.load_image(oracle.encode(np.ascontiguousarray(img[..., :3])))
+    assert got.pixels.shape == (300, 300, 3) and not got.has_transparency  # opaque input => 3 bytes/pixel (SURVEY §8b iii)
+    got = api.load_image(oracle.encode(np.ascontiguousarray(img[..., 1:2])))
+    assert got.pixels.shape == (300, 300, 1) and got.format == "Gray" and got.known_profile == "GraySrgbTRC"
+
+
+def test_callback_failures_map_to_reference_statuses(oracle):
+    data = oracle.encode(synth(300, 300, 3), exif=b"\0\0\0\0II*\0abcd")
+    for cb, status in (("setKnownColorProfile", "CreateMetadataError"), ("setExif", "CreateMetadataError"), ("setLayerData", "CreateLayerError")):
+        with pytest.raises(api.JxlError) as e:
+            api.load_image(data, fail_at=cb)
+        assert e.value.status == status
+
+
+def test_unsupported_streams_fail_loudly(oracle):
+    with pytest.raises(api.FormatError) as e:
+        api.load_image(oracle.encode(synth(300, 300, 4), lossless=True))
+    assert e.value.status == "DecodeError" and "Modular" in str(e.value)
+
+
+def test_save_image_fails_loudly_until_built():
+    bgra = np.zeros((16, 16, 4), np.uint8)
+    with pytest.raises(api.JxlError) as e:
+        api.save_image(bgra)
+    assert e.value.status == "EncodeError"

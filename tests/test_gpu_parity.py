@@ -1,0 +1,162 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): integer/byte work bit-exact — quantised LF, block metadata, quantised HF coefficients,
+alpha; float stages within the tolerances written below; final 8-bit samples within 1 LSB per channel.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+from gpu_helpers import compare_stages, gpu_decode
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_LF = 2e-6          # dequantised LF samples (|values| <= ~1)
+TOL_XYB = 5e-5         # XYB samples after IDCT / loop filters: float32 summation-order differences only
+MAX_LSB = 1            # final u8 samples
+MAX_FRAC_DIFF = 2e-3   # fraction of u8 samples allowed to differ by that one LSB (rounding boundaries)
+
+
+def check_report(rep):
+    for k, v in rep.items():
+        if isinstance(v, bool):
+            assert v, k
+        elif k.startswith("qcoef"):
+            assert v == 0, (k, v)
+        elif k.startswith("lf"):
+            assert v <= TOL_LF, (k, v)
+        else:
+            assert v <= TOL_XYB, (k, v)
+
+
+def check_pixels(out, ref):
+    assert out.shape == ref.shape
+    d = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= MAX_LSB, int(d.max())
+    assert (d > 0).mean() <= MAX_FRAC_DIFF, float((d > 0).mean())
+    if out.shape[2] in (2, 4):
+        assert (out[..., -1] == ref[..., -1]).all()  # alpha: bit-exact
+
+
+def run_case(dec, oracle, img, **enc):
+    data = oracle.encode(img, **enc)
+    od = oracle.decode(data, want_dump=True)
+    out = gpu_decode(dec, [data], taps=True)[0]
+    check_report(compare_stages(dec, 0, od))
+    check_pixels(out, od.pixels)
+    return data, od
+
+
+def test_default_heuristics_rgba(gpu_decoder, oracle):
+    run_case(gpu_decoder, oracle, synth(600, 400, 1))
+
+
+def test_random_mix_of_every_transform(gpu_decoder, oracle):
+    data, od = run_case(gpu_decoder, oracle, synth(776, 520, 2), strategy_mode=2, seed=7)
+    used = set((od.planes["strategy"][od.planes["strategy"] >= 0x80] & 0x7F).tolist())
+    assert len(used) >= 18, used
+
+
+@pytest.mark.parametrize("s", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21, 22, 23, 24, 25, 26])
+def test_each_transform(gpu_decoder, oracle, s):
+    run_case(gpu_decoder, oracle, synth(520, 300, 3), strategy_mode=3, fixed_strategy=s)
+
+
+@pytest.mark.parametrize("size", [(257, 300), (1024, 264), (264, 1100), (300, 257), (2100, 300)])
+def test_ragged_sizes(gpu_decoder, oracle, size):
+    run_case(gpu_decoder, oracle, synth(size[0], size[1], 4))
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3])
+def test_channel_layouts(gpu_decoder, oracle, nch):
+    img = synth(400, 300, 5)
+    run_case(gpu_decoder, oracle, np.ascontiguousarray({3: img[..., :3], 1: img[..., 1:2], 2: img[..., [1, 3]]}[nch]))
+
+
+@pytest.mark.parametrize("epf", [0, 1, 2, 3])
+@pytest.mark.parametrize("gab", [True, False])
+def test_loop_filter_settings(gpu_decoder, oracle, epf, gab):
+    run_case(gpu_decoder, oracle, synth(400, 300, 6), distance=2.5, epf_iters=epf, gaborish=gab)
+
+
+@pytest.mark.parametrize("dist", [0.3, 1.0, 4.0, 12.0])
+def test_distances(gpu_decoder, oracle, dist):
+    run_case(gpu_decoder, oracle, synth(400, 300, 7), distance=dist)
+
+
+def test_without_adaptive_lf_smoothing(gpu_decoder, oracle):
+    run_case(gpu_decoder, oracle, synth(400, 300, 8), adaptive_lf_smoothing=False)
+
+
+def test_noise_image_many_tokens(gpu_decoder, oracle):
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (300, 420, 4), dtype=np.uint8)
+    run_case(gpu_decoder, oracle, img, distance=0.5)
+
+
+def test_flat_image_zero_tokens(gpu_decoder, oracle):
+    img = np.full((300, 420, 4), 200, np.uint8)
+    img[..., 3] = 255
+    img[0, 0, 3] = 254
+    run_case(gpu_decoder, oracle, img)
+
+
+def test_batch_and_lane_mappings_agree(gpu_decoder, oracle):
+    files, refs = [], []
+    for i, (w, h) in enumerate([(600, 400), (300, 700), (1030, 520)]):
+        data = oracle.encode(synth(w, h, 20 + i), strategy_mode=2 if i == 1 else 0, seed=i)
+        files.append(data)
+        refs.append(oracle.decode(data).pixels)
+    base = None
+    for stride in (64, 8, 1):
+        outs = gpu_decode(gpu_decoder, files, lane_stride=stride)
+        for o, r in zip(outs, refs):
+            check_pixels(o, r)
+        if base is None:
+            base = outs
+        else:
+            for a, b in zip(base, outs):
+                assert (a == b).all()  # the mapping of sections to lanes must not change a single bit
+
+
+def test_device_resident_input(gpu_decoder, oracle):
+    data = oracle.encode(synth(500, 400, 9))
+    a = gpu_decode(gpu_decoder, [data])[0]
+    b = gpu_decode(gpu_decoder, [data], resident=True)[0]
+    assert (a == b).all()
+
+
+def test_golden_fixtures_on_gpu(gpu_decoder, oracle):
+    for name in ("rgba_300x280_mix_d2", "rgb_333x257_d1", "gray_270x300_d3"):
+        data = open(os.path.join(GOLD, name + ".jxl"), "rb").read()
+        check_pixels(gpu_decode(gpu_decoder, [data])[0], oracle.decode(data).pixels)
+
+
+def test_full_size_4k_fixture(gpu_decoder, oracle):
+    """BASELINE.json configs[1]: 3840x2160 RGBA8 lossy d=1.  Pixel parity against the oracle plus the
+    size-independent properties: alpha bit-exact and bounded error against the SOURCE image."""
+    data = open(os.path.join(GOLD, "synth_3840x2160_seed2_d1.jxl"), "rb").read()
+    out = gpu_decode(gpu_decoder, [data])[0]
+    ref = oracle.decode(data, num_threads=8).pixels
+    check_pixels(out, ref)
+    src = synth(3840, 2160, 2)
+    assert (out[..., 3] == src[..., 3]).all()
+    mse = ((out[..., :3].astype(np.float64) - src[..., :3]) ** 2).mean()
+    assert 10 * np.log10(255 ** 2 / mse) > 38.0
+
+
+def test_corrupt_stream_is_reported_not_crashing(gpu_decoder, oracle):
+    data = bytearray(oracle.encode(synth(600, 400, 1)))
+    info = api.peek(bytes(data))
+    import torch
+    out = torch.empty(info.width * info.height * info.num_channels, dtype=torch.uint8, device="cuda")
+    # flip bytes in the middle of the last pass group: headers and TOC stay valid
+    for k in range(len(data) - 3000, len(data) - 2900):
+        data[k] ^= 0x5A
+    with pytest.raises(api.FormatError) as e:
+        gpu_decoder.decode_batch([bytes(data)], [out.data_ptr()])
+    assert e.value.status == "DecodeError"

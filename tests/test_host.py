@@ -1,0 +1,124 @@
+"""CPU tests of the product's host side: the C-ABI surface, the host frame parser and its static tables.
+Nothing here launches a kernel."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "jxlfiletypeio.h")).read()
+    names = re.findall(r"JXLFILETYPEIO_API\s+[\w\s\*]+?\b(\w+)\s*\(", hdr)
+    assert {"GetLibJxlVersion", "LoadImage", "SaveImage"} <= set(names)
+    L = api.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    for n in api.EXPORTS:
+        assert n in names, n
+
+
+def test_struct_layouts_match_reference_abi():
+    # sizes from SURVEY.md §8b (reference Common.h / JxlDecoderTypes.h / JxlEncoderTypes.h, LP64 == LLP64)
+    assert C.sizeof(api.BitmapData) == 24
+    assert C.sizeof(api.EncoderOptions) == 12
+    assert C.sizeof(api.EncoderImageMetadata) == 48
+    assert C.sizeof(api.IOCallbacks) == 16
+    assert C.sizeof(api.ErrorInfo) == 256
+    assert C.sizeof(api.DecoderCallbacks) == 48
+    assert api.DECODER_STATUS.index("InvalidFileSignature") == 12 and api.ENCODER_STATUS.index("WriteError") == 5
+
+
+def test_version_is_packed_like_libjxl():
+    major, minor, patch = api.get_libjxl_version()
+    assert (major, minor) >= (0, 10)  # API level the reference's call sites need
+
+
+def test_load_image_parameter_and_signature_errors_need_no_gpu():
+    L = api.lib()
+    err = api.ErrorInfo()
+    assert L.LoadImage(None, b"x", 1, C.byref(err)) == api.DECODER_STATUS.index("NullParameter")
+    with pytest.raises(api.FormatError) as e:
+        api.load_image(b"\x89PNG\r\n\x1a\n" + b"\0" * 64)
+    assert e.value.status == "InvalidFileSignature"
+    with pytest.raises(api.FormatError) as e:
+        api.load_image(b"\xff\x0a")  # signature only: truncated headers
+    assert e.value.status == "DecodeError"
+
+
+def test_save_image_null_parameters():
+    L = api.lib()
+    err = api.ErrorInfo()
+    assert L.SaveImage(None, None, None, None, C.byref(err), api.ProgressFn()) == api.ENCODER_STATUS.index("NullParameter")
+
+
+def test_host_parser_accepts_oracle_streams(oracle):
+    img = synth(600, 400, 1)
+    for kw in (dict(), dict(strategy_mode=2, seed=3), dict(distance=4.0), dict(container=False)):
+        data = oracle.encode(img, **kw)
+        info = api.peek(data)
+        assert (info.width, info.height, info.num_channels, info.has_alpha) == (600, 400, 4, 1)
+        assert info.num_groups == 6 and info.num_lf_groups == 1
+        st, facts, msg = api.parse_check(data)
+        assert st == "Ok", msg
+        assert facts[5] == 7425 and facts[7] == 2 + 1 + 6
+    rgb = oracle.encode(img[..., :3])
+    assert api.peek(rgb).num_channels == 3
+
+
+def test_host_parser_reports_unsupported_paths_loudly(oracle):
+    img = synth(300, 300, 1)
+    st, _, msg = api.parse_check(oracle.encode(img, lossless=True))
+    assert st == "DecodeError" and "Modular" in msg
+    st, _, msg = api.parse_check(oracle.encode(synth(64, 64, 1)))
+    assert st == "DecodeError" and "single-group" in msg
+
+
+def test_host_parser_rejects_truncated_files(oracle):
+    data = oracle.encode(synth(300, 300, 1))
+    for cut in (10, 40, 100, len(data) // 2):
+        st, _, _ = api.parse_check(data[:cut])
+        assert st != "Ok"
+
+
+def test_metadata_boxes_are_located(oracle):
+    exif = b"\0\0\0\0II*\0" + bytes(range(32))
+    data = oracle.encode(synth(300, 300, 1), exif=exif, xmp=b"<xmp/>")
+    assert api.peek(data).width == 300
+
+
+def test_static_tables_match_oracle(oracle):
+    L = oracle.lib()
+    L.jxo_natural_order.restype = C.c_size_t
+    L.jxo_natural_order.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+    L.jxo_dequant_table.restype = C.c_size_t
+    L.jxo_dequant_table.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    bucket_strategy = [0, 1, 4, 5, 6, 8, 10, 18, 19, 21, 22, 24, 25]
+    for o, s in enumerate(bucket_strategy):
+        n = L.jxo_natural_order(s, None, 0)
+        a = np.empty(n, np.uint32)
+        L.jxo_natural_order(s, a.ctypes.data, n)
+        b = api.static_table("natural_order", o, np.uint16)
+        assert sorted(b.tolist()) == list(range(n))  # a permutation
+        assert (a == b).all(), o
+    qt = [0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16]
+    for s in range(27):
+        b = api.static_table("dequant", qt[s], np.float32)
+        n = len(b) // 3
+        for c in range(3):
+            a = np.empty(n, np.float32)
+            L.jxo_dequant_table(s, c, a.ctypes.data, n)
+            assert np.allclose(a, b[c * n:(c + 1) * n], rtol=1e-6), (s, c)
+
+
+def test_golden_files_parse(oracle):
+    for name in ("rgba_300x280_mix_d2", "rgb_333x257_d1", "gray_270x300_d3"):
+        st, facts, msg = api.parse_check(open(os.path.join(GOLD, name + ".jxl"), "rb").read())
+        assert st == "Ok", (name, msg)

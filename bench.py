@@ -8,7 +8,7 @@ value = megapixels decoded per second, whole job (all ranks).  With --gpus N eac
 (weak scaling; independent images shard with no data-path collective — DESIGN.md "Multi-GPU").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (pass_group_kernel: HF-coefficient + alpha entropy decode), bound = HBM;
+  roofline      dominant kernel (the slowest of lf_group_kernel / hf_decode_kernel / alpha_kernel), bound = HBM;
                 achieved = algorithmic bytes per launch (B * (jxl bytes + W*H*4)) / its HIP-event duration
   cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
 """
@@ -120,7 +120,8 @@ def main():
     if rank == 0:
         mp = W * H / 1e6
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        dom = "pass_groups"
+        kernels = {"lf_groups": "lf_group_kernel", "hf_decode": "hf_decode_kernel", "alpha": "alpha_kernel"}
+        dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))   # the dominant kernel of this run
         dom_ms = stage_ms.get(dom, 0.0)
         alg_bytes = B * (len(data) + W * H * C)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -140,7 +141,7 @@ def main():
             "config": {"workload": "3840x2160 RGBA8 lossy VarDCT (distance=1.0) decode, HBM-resident .jxl -> HBM RGBA8",
                        "batch_per_gpu": B, "jxl_bytes": len(data), "groups_per_image": info.num_groups,
                        "lane_stride": args.lane_stride or "auto", "parallelism": "images sharded across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": "pass_group_kernel", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(dom_ms, 4)},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},

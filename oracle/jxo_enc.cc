@@ -43,16 +43,18 @@ struct TreeBuilder {
 
 Tree MakeVarDctTree(uint32_t nlf) {
   TreeBuilder b;
-  // alpha: gradient predictor, contexts by |W-NW| style local gradient magnitude (prop 10 signed => two splits)
-  int a_hi = b.Leaf(5), a_mid = b.Leaf(5), a_lo = b.Leaf(5);
-  int a1 = b.Split(10, -2, a_mid, a_lo);   // W-NW > -2 ? mid : lo
-  int alpha = b.Split(10, 1, a_hi, a1);    // W-NW > 1 ? hi : ...
+  // alpha: one gradient-predicted context (extra local-gradient contexts bought < 0.01 % on the synthetic masks and
+  // cost a tree walk per sample in every decoder)
+  int alpha = b.Leaf(5);
   // LF coefficients
   int lf_b = b.Leaf(5), lf_x = b.Leaf(5), lf_y = b.Leaf(5);
   int lf1 = b.Split(0, 0, lf_x, lf_y);
   int lfn = b.Split(0, 1, lf_b, lf1);
   // HF metadata
-  int sharp = b.Leaf(1), qrow = b.Leaf(1), srow = b.Leaf(0), cfl = b.Leaf(1);
+  // constant maps (EPF sharpness 4, chroma-from-luma 0): Zero predictor + leaf offset => every residual is 0, the
+  // cluster has a single symbol and a decoder can fill the channel without touching the stream
+  int sharp = b.Leaf(0), qrow = b.Leaf(1), srow = b.Leaf(0), cfl = b.Leaf(0);
+  b.t[sharp].offset = 4;
   int binfo = b.Split(2, 0, qrow, srow);
   int m1 = b.Split(0, 1, binfo, cfl);
   int meta = b.Split(0, 2, sharp, m1);

@@ -385,8 +385,8 @@ void TokenizeChannel(const Tree& tree, const WPHeader& wp, const ModularImage& i
   std::vector<int32_t> px = ch.d;
   out.reserve(out.size() + px.size());
   VisitChannel(tree, wp, img.ch, chan, stream_id, px.data(), [&](const TreeNode& leaf, int64_t guess, int32_t actual) -> int32_t {
-    JXO_CHECK(leaf.multiplier == 1 && leaf.offset == 0, "encoder trees use multiplier 1 / offset 0");
-    int64_t res = (int64_t)actual - guess;
+    JXO_CHECK(leaf.multiplier == 1, "encoder trees use multiplier 1");
+    int64_t res = (int64_t)actual - guess - leaf.offset;
     out.emplace_back((uint32_t)leaf.leaf_id, (uint32_t)PackSigned(res));
     return actual;
   });

@@ -72,6 +72,7 @@ struct JxlHipDecoder {
   float* d_basis_all = nullptr;
   float* d_basis_small = nullptr;
   float* d_llf_scale = nullptr;
+  uint16_t* d_natural_small = nullptr;   // buckets 0..8 concatenated (LDS staging source)
   uint16_t* d_natural[kNumOrders] = {};
   float* d_dq[kNumQuantTables] = {};
   uint32_t dq_n[kNumQuantTables] = {};
@@ -133,6 +134,12 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     HIP_OK(hipMalloc(&d_natural[o], st.natural_order[o].size() * 2));
     HIP_OK(hipMemcpy(d_natural[o], st.natural_order[o].data(), st.natural_order[o].size() * 2, hipMemcpyHostToDevice));
   }
+  {
+    std::vector<uint16_t> small_orders;
+    for (int o = 0; o <= 8; o++) small_orders.insert(small_orders.end(), st.natural_order[o].begin(), st.natural_order[o].end());
+    HIP_OK(hipMalloc(&d_natural_small, small_orders.size() * 2));
+    HIP_OK(hipMemcpy(d_natural_small, small_orders.data(), small_orders.size() * 2, hipMemcpyHostToDevice));
+  }
   for (int q = 0; q < kNumQuantTables; q++) {
     HIP_OK(hipMalloc(&d_dq[q], st.dq[q].size() * 4));
     HIP_OK(hipMemcpy(d_dq[q], st.dq[q].data(), st.dq[q].size() * 4, hipMemcpyHostToDevice));
@@ -145,7 +152,7 @@ JxlHipDecoder::~JxlHipDecoder() {
   hipSetDevice(device);
   if (pending) hipStreamSynchronize(last_stream);
   for (auto e : events) hipEventDestroy(e);
-  hipFree(d_basis_all); hipFree(d_basis_small); hipFree(d_llf_scale);
+  hipFree(d_basis_all); hipFree(d_basis_small); hipFree(d_llf_scale); hipFree(d_natural_small);
   for (auto p : d_natural) hipFree(p);
   for (auto p : d_dq) hipFree(p);
   hipFree(d_ws); hipFree(d_blob);
@@ -238,7 +245,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, tmp[3], xyb[3], xyb2[3], inv_sigma, alpha;
+    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, bitpos, tmp[3], xyb[3], xyb2[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
   int total_lf = 0, total_groups = 0;
@@ -271,6 +278,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.ytob = ws.Take(tiles);
     l.binfo = ws.Take((size_t)f.nlf * kBinfoInts * 4);
     l.nzmap = ws.Take((size_t)f.ng * 3072);
+    l.bitpos = ws.Take((size_t)f.ng * 8);
     for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); l.xyb2[c] = ws.Take(4 * pix); }
     l.inv_sigma = ws.Take(4 * cells);
     l.alpha = ws.Take((size_t)f.xsize * f.ysize);
@@ -290,6 +298,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (parse_status[i] == DecoderStatus_Ok) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
+  const int alpha_stride = lane_stride;            // same section -> lane mapping, 64-thread workgroups
+  const int per_alpha_wg = 64 / alpha_stride;
+  int n_alpha_wg = 0;
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
+  const size_t off_alpha_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_alpha_wg));
   const size_t zero_bytes = Align(ws_zero.off, 256);
   EnsureBlob(blob.off);
   EnsureWs(zero_bytes + ws.off);
@@ -303,13 +317,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   memset(h_blob, 0, blob.off);
   imgs.assign(n, DevImage());
   status_off.assign(n, 0);
-  size_t lds_bytes = 0;
-  bool lds_ok = true, any_gab = false, any_alpha = false;
+  size_t lds_hf = 0, lds_lf = 0, lds_alpha = 0;
+  bool any_gab = false, any_alpha = false;
   int max_epf = 0;
   size_t max_cells = 1, max_pix = 1, max_padded = 8;
   SectionTask* lf_tasks = (SectionTask*)(h_blob + off_lf_tasks);
   SectionTask* pass_tasks = (SectionTask*)(h_blob + off_pass_tasks);
-  int nlf_t = 0, npass_t = 0;
+  SectionTask* alpha_tasks = (SectionTask*)(h_blob + off_alpha_tasks);
+  int nlf_t = 0, npass_t = 0, nalpha_t = 0;
   uint8_t* wz = d_ws;
   uint8_t* wr = d_ws + zero_bytes;
   for (int i = 0; i < n; i++) {
@@ -330,7 +345,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     auto code = [&](const HostCode& hc, size_t cm, size_t cf, size_t al, DevCode& dc) {
       put(cm, hc.ctx_map.data(), hc.ctx_map.size());
       std::vector<uint32_t> cfgp(hc.cfg.size());
-      for (size_t k = 0; k < hc.cfg.size(); k++) cfgp[k] = hc.cfg[k].split | hc.cfg[k].msb << 8 | hc.cfg[k].lsb << 16;
+      for (size_t k = 0; k < hc.cfg.size(); k++) {
+        cfgp[k] = hc.cfg[k].split | hc.cfg[k].msb << 4 | hc.cfg[k].lsb << 8;
+        // single-symbol clusters: decoding never changes the ANS state nor reads bits (alias special form)
+        const uint64_t e0 = hc.alias[k << hc.log_alpha];
+        const uint32_t x0 = (uint32_t)e0, y0 = (uint32_t)(e0 >> 32);
+        if ((x0 >> 16) == 0 && (y0 >> 16) == 4096) cfgp[k] |= 1u << 12 | ((x0 >> 8) & 0xFF) << 16;
+      }
       put(cf, cfgp.data(), 4 * cfgp.size());
       put(al, hc.alias.data(), 8 * hc.alias.size());
       dc.ctx_map = d_blob + cm;
@@ -354,11 +375,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.num_block_ctx = f.num_block_ctx;
     memcpy(d.block_ctx_map, f.block_ctx_map.data(), std::min(sizeof(d.block_ctx_map), f.block_ctx_map.size()));
     d.n_qf = (int32_t)f.qf_thr.size();
+    d.custom_orders = 0;
     for (size_t k = 0; k < f.qf_thr.size() && k < 15; k++) d.qf_thr[k] = f.qf_thr[k];
     for (int o = 0; o < kNumOrders; o++)
       for (int c = 0; c < 3; c++) {
         if (f.custom_order[o][c].empty()) d.order[o * 3 + c] = d_natural[o];
-        else { put(l.order[o][c], f.custom_order[o][c].data(), 2 * f.custom_order[o][c].size()); d.order[o * 3 + c] = (const uint16_t*)(d_blob + l.order[o][c]); }
+        else { put(l.order[o][c], f.custom_order[o][c].data(), 2 * f.custom_order[o][c].size()); d.order[o * 3 + c] = (const uint16_t*)(d_blob + l.order[o][c]); d.custom_orders = 1; }
       }
     d.inv_global_scale = 65536.0f / f.global_scale;
     d.quant_scale = f.global_scale / 65536.0f;
@@ -395,7 +417,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.lf_extra = wr + l.lf_extra;
     d.rawq = (uint16_t*)(wr + l.rawq); d.sharp = wr + l.sharp;
     d.ytox = (int8_t*)(wr + l.ytox); d.ytob = (int8_t*)(wr + l.ytob);
-    d.binfo = (int32_t*)(wr + l.binfo); d.nzmap = wr + l.nzmap;
+    d.binfo = (int32_t*)(wr + l.binfo); d.nzmap = wr + l.nzmap; d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
     d.alpha32 = (int32_t*)d.tmp[0];
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
@@ -418,14 +440,16 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     max_cells = std::max(max_cells, (size_t)f.w8 * f.h8);
     max_pix = std::max(max_pix, (size_t)f.xsize * f.ysize);
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
-    // LDS budget of the pass-group kernel
-    size_t lds = 8 * (f.acode.alias.size() + f.mcode.alias.size());
-    lds = Align(lds, 16) + sizeof(DevTreeNode) * f.tree.size() + 4 * (f.acode.cfg.size() + f.mcode.cfg.size()) +
-          f.acode.ctx_map.size() + f.mcode.ctx_map.size() + 64;
-    if (lds > 64 * 1024) lds_ok = false;
-    lds_bytes = std::max(lds_bytes, lds);
+    // LDS budgets (must mirror the carving in entropy_kernels.hip)
+    auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
+    lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64);
+    lds_lf = std::max(lds_lf, 1024 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_alpha = std::max(lds_alpha, (size_t)(64 / alpha_stride) * 1024 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
     for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
+    if (d.has_alpha)
+      for (uint32_t g = 0; g < f.ng; g += per_alpha_wg)
+        alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, f.ng - g), 0};
   }
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
   d_imgs = (DevImage*)(d_blob + off_imgs);
@@ -435,12 +459,17 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, stream));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, stream));
   Mark("upload+clear", stream);
-  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, stream);
+  const size_t kLdsMax = 150 * 1024;
+  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, lds_lf <= kLdsMax ? lds_lf : 0, stream);
   Mark("lf_groups", stream);
   LaunchLfPixelStages(d_imgs, n, max_cells, stream);
   Mark("lf_pixels", stream);
-  LaunchPassGroups(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_ok ? lds_bytes : 0, stream);
-  Mark("pass_groups", stream);
+  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_hf <= kLdsMax ? lds_hf : 0, d_natural_small,
+                 stream);
+  Mark("hf_decode", stream);
+  if (any_alpha)
+    LaunchAlpha(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
+  Mark("alpha", stream);
   if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
   if (any_alpha) LaunchAlphaToU8(d_imgs, n, max_pix, stream);
   LaunchReconstruct(d_imgs, n, max_padded, max_cells, d_basis_all, d_basis_small, d_llf_scale, stream);

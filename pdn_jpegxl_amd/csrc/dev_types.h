@@ -34,7 +34,7 @@ struct DevTreeNode {    // 16 bytes
 
 struct DevCode {
   const uint8_t* ctx_map;
-  const uint32_t* cfg;      // per cluster: split_exponent | msb << 8 | lsb << 16
+  const uint32_t* cfg;      // per cluster: split_exponent | msb << 4 | lsb << 8 | degenerate << 12 | symbol << 16
   const uint64_t* alias;    // [cluster << log_alpha | i]: low32 = cutoff | right << 8 | freq0 << 16, high32 = offsets1 | (freq1^freq0) << 16
   uint32_t num_ctx;
   uint32_t num_clusters;
@@ -63,6 +63,7 @@ struct DevImage {
   uint8_t block_ctx_map[39 * 16];   // [(c'*13 + ord) * (nqf+1) + qf_idx]
   uint32_t qf_thr[15];
   int32_t n_qf;
+  int32_t custom_orders;    // any non-natural coefficient order in this frame
   const uint16_t* order[kNumOrders * 3];   // coefficient order per (bucket, channel)
   // quantisation
   float inv_global_scale, quant_scale;
@@ -94,6 +95,7 @@ struct DevImage {
   int8_t* ytob;
   int32_t* binfo;           // scratch per LF group (kBinfoInts ints): cfl x, cfl b, block info rows, sharpness
   uint8_t* nzmap;           // scratch per group: 3 * 1024 bytes (non-zero counts per 8x8 cell)
+  uint64_t* grp_bitpos;     // per group: codestream bit position after the HF tokens (~0 = failed)
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
   int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
   float* tmp[3];            // wp*hp

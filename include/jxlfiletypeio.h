@@ -166,11 +166,16 @@ JXLFILETYPEIO_API size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, co
                                            size_t capacity);
 
 /* Options: "debug_taps" (0/1: keep qcoef / xyb_idct / xyb_filtered stage copies; slow), "lane_stride" (0 = auto,
- * 64 = one section per wavefront ... 1 = one section per lane).  Returns 1 if the option exists. */
+ * 64 = one section per wavefront ... 1 = one section per lane), "overlap" (0/1: run the LF stage of the next
+ * asynchronous batch on a second stream while the previous batch finishes).  Returns 1 if the option exists. */
 JXLFILETYPEIO_API int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value);
 
 /* Timing of the last synchronised batch: milliseconds per named stage (HIP events on the decode stream). */
 JXLFILETYPEIO_API int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity);
+
+/* Cumulative per-stage time over every batch finished since the last reset (asynchronous batches included). */
+JXLFILETYPEIO_API int32_t jxlhip_stage_totals(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity, int32_t* batches,
+                                              int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -65,7 +65,7 @@ class ImageInfo(C.Structure):
 
 
 EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_decoder_create", "jxlhip_decoder_destroy", "jxlhip_peek",
-           "jxlhip_decode_batch", "jxlhip_finish", "jxlhip_read_plane", "jxlhip_set_option", "jxlhip_stage_times"]
+           "jxlhip_decode_batch", "jxlhip_finish", "jxlhip_read_plane", "jxlhip_set_option", "jxlhip_stage_times", "jxlhip_stage_totals"]
 
 _lib = None
 
@@ -116,6 +116,8 @@ def lib(build_if_missing=True):
     L.jxlhip_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int32]
     L.jxlhip_stage_times.restype = C.c_int32
     L.jxlhip_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int32]
+    L.jxlhip_stage_totals.restype = C.c_int32
+    L.jxlhip_stage_totals.argtypes = [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32), C.c_int32]
     L.jxlhip_parse_check.restype = C.c_int32
     L.jxlhip_parse_check.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(ErrorInfo)]
     L.jxlhip_static_table.restype = C.c_size_t
@@ -311,6 +313,7 @@ class Decoder:
         return list(st)
 
     def finish(self):
+        """Waits for every asynchronous batch; raises if any of them failed."""
         err = ErrorInfo()
         r = self._L.jxlhip_finish(self._h, None, C.byref(err))
         if r != 0:
@@ -323,6 +326,14 @@ class Decoder:
         buf = np.empty(n // np.dtype(_PLANE_DTYPES[name]).itemsize, _PLANE_DTYPES[name])
         self._L.jxlhip_read_plane(self._h, index, name.encode(), channel, buf.ctypes.data, n)
         return buf
+
+    def stage_totals(self, reset=False):
+        """({stage: cumulative ms}, batches) over every batch finished since the last reset."""
+        names = (C.c_char_p * 16)()
+        ms = (C.c_float * 16)()
+        nb = C.c_int32()
+        k = self._L.jxlhip_stage_totals(self._h, names, ms, 16, C.byref(nb), 1 if reset else 0)
+        return {names[i].decode(): ms[i] for i in range(k)}, nb.value
 
     def stage_times(self):
         names = (C.c_char_p * 16)()

@@ -76,36 +76,54 @@ struct JxlHipDecoder {
   uint16_t* d_natural[kNumOrders] = {};
   float* d_dq[kNumQuantTables] = {};
   uint32_t dq_n[kNumQuantTables] = {};
-  // grow-only buffers
-  uint8_t* d_ws = nullptr; size_t ws_cap = 0;        // planes
-  uint8_t* d_blob = nullptr; size_t blob_cap = 0;    // tables / descriptors / uploaded bitstreams
-  uint8_t* h_blob = nullptr; size_t h_blob_cap = 0;  // pinned mirror of d_blob
-  uint32_t* h_status = nullptr; size_t h_status_cap = 0;
-  // last batch
-  int n = 0;
-  std::vector<ParsedFrame> frames;
-  std::vector<DevImage> imgs;          // host copies (device pointers inside)
-  std::vector<int> parse_status;
-  std::vector<std::string> parse_msg;
-  std::vector<size_t> status_off;      // offset of each image's status words in the workspace
-  DevImage* d_imgs = nullptr;
+  // Per-batch state lives in one of two slots so that the LF stage of batch k+1 (stream_lf) overlaps the HF and pixel
+  // stages of batch k (main stream) when the caller does not synchronise between batches.
+  struct Tap { std::vector<uint8_t> qcoef[3], xyb_idct[3], xyb_filtered[3]; };
+  struct Slot {
+    // grow-only buffers
+    uint8_t* d_ws = nullptr; size_t ws_cap = 0;        // planes
+    uint8_t* d_blob = nullptr; size_t blob_cap = 0;    // tables / descriptors / uploaded bitstreams
+    uint8_t* h_blob = nullptr; size_t h_blob_cap = 0;  // pinned mirror of d_blob
+    uint32_t* h_status = nullptr; size_t h_status_cap = 0;
+    int n = 0;
+    std::vector<ParsedFrame> frames;
+    std::vector<DevImage> imgs;          // host copies (device pointers inside)
+    std::vector<int> parse_status;
+    std::vector<std::string> parse_msg;
+    std::vector<size_t> status_off;      // offset of each image's status words in the workspace
+    DevImage* d_imgs = nullptr;
+    bool pending = false;
+    hipEvent_t lf_done = nullptr, done = nullptr;
+    std::vector<Tap> taps;
+    // timing: two event chains (LF stream, main stream)
+    std::vector<std::string> stage_names;
+    std::vector<int> stage_chain;
+    std::vector<hipEvent_t> events;
+    std::vector<float> stage_ms;
+  };
+  Slot slots[2];
+  int cur = 0, last = 0;
+  Slot* active = &slots[0];
+  hipStream_t stream_lf = nullptr;
   hipStream_t last_stream = nullptr;
-  bool pending = false;
+  // cumulative per-stage HIP-event time over every finished batch since the last reset (bench: timed region)
+  std::vector<std::string> total_names;
+  std::vector<double> total_ms;
+  int total_batches = 0;
+  std::string sticky_error;             // failure of an older, not yet reported batch
+  int sticky_status = 0;
   // options
   int lane_stride_override = 0;
   bool debug_taps = false;
-  struct Tap { std::vector<uint8_t> qcoef[3], xyb_idct[3], xyb_filtered[3]; };
-  std::vector<Tap> taps;
-  // timing
-  std::vector<std::string> stage_names;
-  std::vector<hipEvent_t> events;
-  std::vector<float> stage_ms;
+  bool overlap = true;
 
   explicit JxlHipDecoder(int dev);
   ~JxlHipDecoder();
   void EnsureWs(size_t bytes);
   void EnsureBlob(size_t bytes);
-  void Mark(const char* name, hipStream_t s);
+  void Mark(const char* name, hipStream_t s, int chain);
+  void WaitSlot(Slot& S);
+  Slot& Last() { return slots[last]; }
   void Decode(int32_t n_, const uint8_t* const* host_data, const size_t* sizes, const uint8_t* const* dev_data,
               uint8_t* const* dev_out, hipStream_t stream, bool sync, DecoderStatus* statuses, ErrorInfo* err);
   DecoderStatus Finish(DecoderStatus* statuses, ErrorInfo* err);
@@ -117,6 +135,12 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   device = dev;
   HIP_OK(hipSetDevice(device));
   HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&stream_lf, hipStreamNonBlocking));
+  for (auto& S : slots) {
+    HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+  }
+  if (const char* e = getenv("JXLHIP_NO_OVERLAP")) overlap = atoi(e) == 0;
   const StaticTables& st = GetStaticTables();
   std::vector<float> all;
   for (int i = 0; i < 6; i++) all.insert(all.end(), st.basis[i].begin(), st.basis[i].end());
@@ -149,19 +173,25 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
 }
 
 JxlHipDecoder::~JxlHipDecoder() {
-  hipSetDevice(device);
-  if (pending) hipStreamSynchronize(last_stream);
-  for (auto e : events) hipEventDestroy(e);
-  hipFree(d_basis_all); hipFree(d_basis_small); hipFree(d_llf_scale); hipFree(d_natural_small);
-  for (auto p : d_natural) hipFree(p);
-  for (auto p : d_dq) hipFree(p);
-  hipFree(d_ws); hipFree(d_blob);
-  if (h_blob) hipHostFree(h_blob);
-  if (h_status) hipHostFree(h_status);
-  if (own_stream) hipStreamDestroy(own_stream);
+  (void)hipSetDevice(device);
+  (void)hipDeviceSynchronize();
+  for (auto& S : slots) {
+    for (auto e : S.events) (void)hipEventDestroy(e);
+    if (S.lf_done) (void)hipEventDestroy(S.lf_done);
+    if (S.done) (void)hipEventDestroy(S.done);
+    (void)hipFree(S.d_ws); (void)hipFree(S.d_blob);
+    if (S.h_blob) (void)hipHostFree(S.h_blob);
+    if (S.h_status) (void)hipHostFree(S.h_status);
+  }
+  (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_llf_scale); (void)hipFree(d_natural_small);
+  for (auto p : d_natural) (void)hipFree(p);
+  for (auto p : d_dq) (void)hipFree(p);
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+  if (stream_lf) (void)hipStreamDestroy(stream_lf);
 }
 
 void JxlHipDecoder::EnsureWs(size_t bytes) {
+  auto& d_ws = active->d_ws; auto& ws_cap = active->ws_cap;
   if (bytes <= ws_cap) return;
   if (d_ws) HIP_OK(hipFree(d_ws));
   d_ws = nullptr;
@@ -172,6 +202,7 @@ void JxlHipDecoder::EnsureWs(size_t bytes) {
 }
 
 void JxlHipDecoder::EnsureBlob(size_t bytes) {
+  auto& d_blob = active->d_blob; auto& blob_cap = active->blob_cap; auto& h_blob = active->h_blob; auto& h_blob_cap = active->h_blob_cap;
   if (bytes > blob_cap) {
     if (d_blob) HIP_OK(hipFree(d_blob));
     d_blob = nullptr;
@@ -190,22 +221,56 @@ void JxlHipDecoder::EnsureBlob(size_t bytes) {
   }
 }
 
-void JxlHipDecoder::Mark(const char* name, hipStream_t s) {
-  size_t i = stage_names.size();
-  stage_names.push_back(name);
-  if (events.size() <= i) {
+void JxlHipDecoder::Mark(const char* name, hipStream_t s, int chain) {
+  Slot& S = *active;
+  size_t i = S.stage_names.size();
+  S.stage_names.push_back(name);
+  S.stage_chain.push_back(chain);
+  if (S.events.size() <= i) {
     hipEvent_t e;
     HIP_OK(hipEventCreate(&e));
-    events.push_back(e);
+    S.events.push_back(e);
   }
-  HIP_OK(hipEventRecord(events[i], s));
+  HIP_OK(hipEventRecord(S.events[i], s));
+}
+
+// Waits for a submitted batch and folds a failure into the sticky error (reported by the next Finish).
+void JxlHipDecoder::WaitSlot(Slot& S) {
+  if (!S.pending) return;
+  HIP_OK(hipEventSynchronize(S.done));
+  S.pending = false;
+  S.stage_ms.assign(S.stage_names.size(), 0.f);
+  for (size_t i = 1; i < S.stage_names.size(); i++)
+    if (S.stage_chain[i] == S.stage_chain[i - 1]) (void)hipEventElapsedTime(&S.stage_ms[i], S.events[i - 1], S.events[i]);
+  for (size_t i = 1; i < S.stage_names.size(); i++) {
+    if (S.stage_chain[i] != S.stage_chain[i - 1]) continue;
+    size_t k = 0;
+    while (k < total_names.size() && total_names[k] != S.stage_names[i]) k++;
+    if (k == total_names.size()) { total_names.push_back(S.stage_names[i]); total_ms.push_back(0.0); }
+    total_ms[k] += S.stage_ms[i];
+  }
+  total_batches++;
 }
 
 void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const size_t* sizes, const uint8_t* const* dev_data,
                            uint8_t* const* dev_out, hipStream_t stream, bool sync, DecoderStatus* statuses, ErrorInfo* err) {
   HIP_OK(hipSetDevice(device));
-  if (pending) { HIP_OK(hipStreamSynchronize(last_stream)); pending = false; }
   if (!stream) stream = own_stream;
+  Slot& S = slots[cur];
+  active = &S;
+  if (S.pending) {
+    // the slot is reused: its previous batch must be complete; remember a failure nobody has looked at yet
+    WaitSlot(S);
+    for (int i = 0; i < S.n; i++) {
+      int st = S.parse_status[i];
+      if (st == DecoderStatus_Ok && S.h_status[(size_t)i * 16]) st = DecoderStatus_DecodeError;
+      if (st != DecoderStatus_Ok && sticky_status == DecoderStatus_Ok) { sticky_status = st; sticky_error = "an earlier asynchronous batch failed: " + S.parse_msg[i]; }
+    }
+  }
+  auto& d_ws = S.d_ws; auto& d_blob = S.d_blob; auto& h_blob = S.h_blob; auto& h_status = S.h_status; auto& h_status_cap = S.h_status_cap;
+  auto& n = S.n; auto& frames = S.frames; auto& imgs = S.imgs; auto& parse_status = S.parse_status; auto& parse_msg = S.parse_msg;
+  auto& status_off = S.status_off; auto& d_imgs = S.d_imgs; auto& taps = S.taps; auto& stage_names = S.stage_names;
+  hipStream_t s_lf = (overlap && !debug_taps) ? stream_lf : stream;
   n = n_;
   frames.assign(n, ParsedFrame());
   parse_status.assign(n, DecoderStatus_Ok);
@@ -245,7 +310,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, bitpos, tmp[3], xyb[3], xyb2[3], inv_sigma, alpha;
+    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
   int total_lf = 0, total_groups = 0;
@@ -279,18 +344,25 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.binfo = ws.Take((size_t)f.nlf * kBinfoInts * 4);
     l.nzmap = ws.Take((size_t)f.ng * 3072);
     l.bitpos = ws.Take((size_t)f.ng * 8);
-    for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); l.xyb2[c] = ws.Take(4 * pix); }
+    l.tile_list = ws.Take(tiles * 4);
+    for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); }
     l.inv_sigma = ws.Take(4 * cells);
     l.alpha = ws.Take((size_t)f.xsize * f.ysize);
     total_lf += f.nlf;
     total_groups += f.ng;
   }
-  // lane mapping of the pass-group kernel
+  // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
+  // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
   int lane_stride = 64;
   if (lane_stride_override > 0) lane_stride = lane_stride_override;
   else {
-    int waves_wanted = total_groups;     // at stride 64
-    while (lane_stride > 1 && waves_wanted > 4096) { lane_stride >>= 1; waves_wanted >>= 1; }
+    size_t lds_est = 0;
+    for (int i = 0; i < n; i++)
+      if (parse_status[i] == DecoderStatus_Ok)
+        lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 2 + 8448 * 2 + 64);
+    const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
+    const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
+    while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
   }
   const int per_wg = 256 / lane_stride;
   int n_pass_wg = 0;
@@ -318,7 +390,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   imgs.assign(n, DevImage());
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_lf = 0, lds_alpha = 0;
-  bool any_gab = false, any_alpha = false;
+  bool any_gab = false, any_alpha = false, any_unfiltered = false;
+  int max_w = 1, max_h = 1, max_tiles = 1;
+  auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
   size_t max_cells = 1, max_pix = 1, max_padded = 8;
   SectionTask* lf_tasks = (SectionTask*)(h_blob + off_lf_tasks);
@@ -412,12 +486,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.coef[c] = (int32_t*)(wz + l.z_coef[c]);
       d.lf[c] = (float*)(wr + l.lf[c]); d.lf_tmp[c] = (float*)(wr + l.lf_tmp[c]); d.lfq[c] = (int32_t*)(wr + l.lfq[c]);
       d.lf_final[c] = d.skip_lf_smoothing ? d.lf[c] : d.lf_tmp[c];
-      d.tmp[c] = (float*)(wr + l.tmp[c]); d.xyb[c] = (float*)(wr + l.xyb[c]); d.xyb2[c] = (float*)(wr + l.xyb2[c]);
+      d.tmp[c] = (float*)(wr + l.tmp[c]); d.xyb[c] = (float*)(wr + l.xyb[c]);
+      d.xyb2[c] = (float*)d.coef[c];   // the coefficient planes are dead once the frame is reconstructed: loop-filter ping-pong buffer
     }
     d.lf_extra = wr + l.lf_extra;
     d.rawq = (uint16_t*)(wr + l.rawq); d.sharp = wr + l.sharp;
     d.ytox = (int8_t*)(wr + l.ytox); d.ytob = (int8_t*)(wr + l.ytob);
     d.binfo = (int32_t*)(wr + l.binfo); d.nzmap = wr + l.nzmap; d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
+    d.tile_list = (uint32_t*)(wr + l.tile_list);
     d.alpha32 = (int32_t*)d.tmp[0];
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
@@ -434,6 +510,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (int c = 0; c < 3; c++) { d.stage_in[s][c] = cur[c]; d.stage_out[s][c] = other[c]; }
       if (s < 4 && d.stage_on[s]) std::swap(cur, other);
     }
+    d.final_stage = 4;
+    for (int s = 0; s < 4; s++) if (d.stage_on[s]) d.final_stage = s;
+    if (debug_taps) d.final_stage = 4;   // keep the filtered float planes for the stage taps; out_only_kernel converts
+    any_unfiltered |= d.final_stage == 4;
+    max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
+    max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));
     any_gab |= f.gab;
     any_alpha |= d.has_alpha != 0;
     max_epf = std::max<int>(max_epf, f.epf_iters);
@@ -443,8 +525,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
     lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64);
-    lds_lf = std::max(lds_lf, 1024 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
-    lds_alpha = std::max(lds_alpha, (size_t)(64 / alpha_stride) * 1024 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_lf = std::max(lds_lf, 1024 + 64 * 256 * 4 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_alpha = std::max(lds_alpha, (size_t)(64 / alpha_stride) * 1024 + (alpha_stride == 64 ? 64 * 256 * 4 : 0) +
+                                        sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
     for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
     if (d.has_alpha)
@@ -453,33 +536,47 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
   d_imgs = (DevImage*)(d_blob + off_imgs);
-  // ---- 4. enqueue
+  // ---- 4. enqueue: LF chain on s_lf, everything that needs the block layout on the main stream
   stage_names.clear();
-  Mark("start", stream);
-  HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, stream));
-  HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, stream));
-  Mark("upload+clear", stream);
+  S.stage_chain.clear();
+  Mark("start", s_lf, 0);
+  HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
+  HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
+  Mark("upload+clear", s_lf, 0);
   const size_t kLdsMax = 150 * 1024;
-  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, lds_lf <= kLdsMax ? lds_lf : 0, stream);
-  Mark("lf_groups", stream);
-  LaunchLfPixelStages(d_imgs, n, max_cells, stream);
-  Mark("lf_pixels", stream);
+  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
+  Mark("lf_groups", s_lf, 0);
+  LaunchLfPixelStages(d_imgs, n, max_cells, s_lf);
+  Mark("lf_pixels", s_lf, 0);
+  if (s_lf != stream) {
+    HIP_OK(hipEventRecord(S.lf_done, s_lf));
+    HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0));
+  }
+  Mark("main_start", stream, 1);
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_hf <= kLdsMax ? lds_hf : 0, d_natural_small,
                  stream);
-  Mark("hf_decode", stream);
+  Mark("hf_decode", stream, 1);
   if (any_alpha)
     LaunchAlpha(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
-  Mark("alpha", stream);
+  Mark("alpha", stream, 1);
   if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
   if (any_alpha) LaunchAlphaToU8(d_imgs, n, max_pix, stream);
-  LaunchReconstruct(d_imgs, n, max_padded, max_cells, d_basis_all, d_basis_small, d_llf_scale, stream);
-  Mark("reconstruct", stream);
+  LaunchReconTiles(d_imgs, n, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
+  LaunchGenericReconstruct(d_imgs, n, d_basis_all, d_basis_small, d_llf_scale, stream);
+  Mark("reconstruct", stream, 1);
   if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
-  LaunchFiltersAndOutput(d_imgs, n, max_pix, any_gab, max_epf, stream);
-  Mark("filters+output", stream);
+  LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, stream);
+  Mark("filters+output", stream, 1);
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok)
+      HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipEventRecord(S.done, stream));
   HIP_OK(hipGetLastError());
   last_stream = stream;
-  pending = true;
+  S.pending = true;
+  last = cur;
+  cur ^= 1;
+  (void)max_padded;
   if (sync) {
     DecoderStatus st = Finish(statuses, err);
     (void)st;
@@ -490,6 +587,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
 }
 
 void JxlHipDecoder::CopyPlaneTap(int stage) {
+  Slot& S = *active;
+  auto& n = S.n; auto& parse_status = S.parse_status; auto& imgs = S.imgs; auto& taps = S.taps;
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
     const DevImage& d = imgs[i];
@@ -505,21 +604,25 @@ void JxlHipDecoder::CopyPlaneTap(int stage) {
 
 DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
   HIP_OK(hipSetDevice(device));
-  if (!pending) return DecoderStatus_Ok;
-  for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok)
-      HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, last_stream));
-  HIP_OK(hipStreamSynchronize(last_stream));
-  pending = false;
-  stage_ms.assign(stage_names.size(), 0.f);
-  for (size_t i = 1; i < stage_names.size(); i++) hipEventElapsedTime(&stage_ms[i], events[i - 1], events[i]);
+  // older batch first (its failure, if any, becomes the sticky error), then the most recent one
+  Slot& O = slots[last ^ 1];
+  if (O.pending) {
+    WaitSlot(O);
+    for (int i = 0; i < O.n; i++) {
+      int st = O.parse_status[i];
+      if (st == DecoderStatus_Ok && O.h_status[(size_t)i * 16]) st = DecoderStatus_DecodeError;
+      if (st != DecoderStatus_Ok && sticky_status == DecoderStatus_Ok) { sticky_status = st; sticky_error = "an earlier asynchronous batch failed: " + O.parse_msg[i]; }
+    }
+  }
+  Slot& S = Last();
+  WaitSlot(S);
   DecoderStatus worst = DecoderStatus_Ok;
-  for (int i = 0; i < n; i++) {
-    DecoderStatus st = parse_status[i];
+  for (int i = 0; i < S.n; i++) {
+    DecoderStatus st = S.parse_status[i];
     if (st != DecoderStatus_Ok) {
-      if (worst == DecoderStatus_Ok) SetErr(err, "%s", parse_msg[i].c_str());
-    } else if (h_status[(size_t)i * 16]) {
-      uint32_t bits = h_status[(size_t)i * 16];
+      if (worst == DecoderStatus_Ok) SetErr(err, "%s", S.parse_msg[i].c_str());
+    } else if (S.h_status[(size_t)i * 16]) {
+      uint32_t bits = S.h_status[(size_t)i * 16];
       st = DecoderStatus_DecodeError;
       if (worst == DecoderStatus_Ok)
         SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
@@ -529,6 +632,12 @@ DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
     if (statuses) statuses[i] = st;
     if (st != DecoderStatus_Ok && worst == DecoderStatus_Ok) worst = st;
   }
+  if (worst == DecoderStatus_Ok && sticky_status != DecoderStatus_Ok) {
+    worst = sticky_status;
+    SetErr(err, "%s", sticky_error.c_str());
+  }
+  sticky_status = DecoderStatus_Ok;
+  sticky_error.clear();
   return worst;
 }
 
@@ -603,13 +712,16 @@ int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
   if (!dec || !name) return 0;
   if (!strcmp(name, "debug_taps")) { dec->debug_taps = value != 0; return 1; }
   if (!strcmp(name, "lane_stride")) { dec->lane_stride_override = value; return 1; }
+  if (!strcmp(name, "overlap")) { dec->overlap = value != 0; return 1; }
   return 0;
 }
 
 size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, const char* name, int32_t channel, void* dst, size_t capacity) {
-  if (!dec || index < 0 || index >= dec->n || !name || dec->pending) return 0;
-  if (dec->parse_status[index] != DecoderStatus_Ok) return 0;
-  const DevImage& d = dec->imgs[index];
+  if (!dec || !name) return 0;
+  JxlHipDecoder::Slot& S = dec->Last();
+  if (index < 0 || index >= S.n || S.pending) return 0;
+  if (S.parse_status[index] != DecoderStatus_Ok) return 0;
+  const DevImage& d = S.imgs[index];
   std::string nm(name);
   const size_t cells = (size_t)d.w8 * d.h8, pix = (size_t)d.wp * d.hp;
   const void* src = nullptr;
@@ -625,11 +737,11 @@ size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, const char* name, in
   else if (nm == "ytob") { src = d.ytob; bytes = (size_t)d.wt * d.ht; }
   else if (nm == "alpha") { src = d.alpha; bytes = (size_t)d.w * d.h; }
   else if (nm == "inv_sigma") { src = d.inv_sigma; bytes = cells * 4; }
-  else if (dec->debug_taps && (size_t)index < dec->taps.size()) {
+  else if (dec->debug_taps && (size_t)index < S.taps.size()) {
     host = true;
-    if (nm == "qcoef") { src = dec->taps[index].qcoef[c].data(); bytes = dec->taps[index].qcoef[c].size(); }
-    else if (nm == "xyb_idct") { src = dec->taps[index].xyb_idct[c].data(); bytes = dec->taps[index].xyb_idct[c].size(); }
-    else if (nm == "xyb_filtered") { src = dec->taps[index].xyb_filtered[c].data(); bytes = dec->taps[index].xyb_filtered[c].size(); }
+    if (nm == "qcoef") { src = S.taps[index].qcoef[c].data(); bytes = S.taps[index].qcoef[c].size(); }
+    else if (nm == "xyb_idct") { src = S.taps[index].xyb_idct[c].data(); bytes = S.taps[index].xyb_idct[c].size(); }
+    else if (nm == "xyb_filtered") { src = S.taps[index].xyb_filtered[c].data(); bytes = S.taps[index].xyb_filtered[c].size(); }
   }
   (void)pix;
   if (!src || !bytes) return 0;
@@ -643,11 +755,28 @@ size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, const char* name, in
 
 int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity) {
   if (!dec) return 0;
+  JxlHipDecoder::Slot& S = dec->Last();
   int32_t k = 0;
-  for (size_t i = 1; i < dec->stage_names.size() && i < dec->stage_ms.size() && k < capacity; i++, k++) {
-    if (names) names[k] = dec->stage_names[i].c_str();
-    if (ms) ms[k] = dec->stage_ms[i];
+  for (size_t i = 1; i < S.stage_names.size() && i < S.stage_ms.size() && k < capacity; i++) {
+    if (S.stage_chain[i] != S.stage_chain[i - 1]) continue;
+    if (names) names[k] = S.stage_names[i].c_str();
+    if (ms) ms[k] = S.stage_ms[i];
+    k++;
   }
+  return k;
+}
+
+// Cumulative stage times over all batches finished since the last reset; returns the number of stages, *batches = batch count.
+JXLFILETYPEIO_API int32_t jxlhip_stage_totals(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity, int32_t* batches,
+                                              int32_t reset) {
+  if (!dec) return 0;
+  int32_t k = 0;
+  for (size_t i = 0; i < dec->total_names.size() && k < capacity; i++, k++) {
+    if (names) names[k] = dec->total_names[i].c_str();
+    if (ms) ms[k] = (float)dec->total_ms[i];
+  }
+  if (batches) *batches = dec->total_batches;
+  if (reset) { dec->total_names.clear(); dec->total_ms.clear(); dec->total_batches = 0; }
   return k;
 }
 

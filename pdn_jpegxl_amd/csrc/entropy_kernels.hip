@@ -351,6 +351,83 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
   }
 }
 
+// Resolves the MA tree of (chan, stream_id) on static properties only.  Returns true when that already ends in a
+// leaf, i.e. neither the context nor the predictor of any sample depends on decoded samples or on the position.
+template <bool kLds>
+__device__ bool StaticLeaf(typename AS<kLds>::Tree tree, int chan, int stream_id, DevTreeNode* leaf) {
+  int root = 0;
+  DevTreeNode nd = NodeOf(tree[0]);
+  while (nd.property == 0 || nd.property == 1) {
+    const int v = nd.property == 0 ? chan : stream_id;
+    root = v > nd.splitval ? nd.a : nd.b;
+    nd = NodeOf(tree[root]);
+  }
+  *leaf = nd;
+  return nd.property < 0;
+}
+
+// Split-phase decode of one channel by a whole wavefront (64 lanes, LDS variant only).  Precondition: StaticLeaf()
+// holds with predictor Zero / W / N / Gradient and w <= 256.  Per batch of up to 64 rows:
+//   phase A (lane 0): the serial part — ANS + hybrid-uint tokens -> residuals in LDS (`resid`, 64 x 256);
+//   phase B (all lanes): lane r reconstructs row r, skewed by one sample per row, so that N comes from lane r-1's
+//            previous step (one DPP shuffle), NW is the lane's own previous N and W its own previous value.
+// `b` and `state` are meaningful in lane 0 only.  rb: LDS row (>= w ints) carrying the last row between batches.
+__device__ void ModularChannelWave(LaneBits& b, uint32_t& state, const CodeTab<true>& tab, const DevTreeNode& leaf, int w, int h,
+                                   int32_t* out_generic, int stride, JXL_LDS int32_t* rb, JXL_LDS int32_t* resid, int lane) {
+  JXL_GLB int32_t* const out = G(out_generic);
+  const uint32_t pred = leaf.a & 0xFF;
+  const uint32_t cl = tab.cmap[leaf.a >> 8];
+  const uint32_t cfg = tab.cfg[cl];
+  const AS<true>::U64 abase = tab.alias + (cl << tab.log_alpha);
+  const bool constant_token = (cfg & 0x1000) && ((cfg >> 16) & 0xFF) < (1u << (cfg & 0xF));
+  const uint32_t const_res = (uint32_t)UnpackSigned((cfg >> 16) & 0xFF) * leaf.b + (uint32_t)leaf.splitval;
+  for (int y0 = 0; y0 < h; y0 += 64) {
+    const int nrows = min(64, h - y0);
+    if (lane == 0 && !constant_token) {
+      const int n = nrows * w;
+      int x = 0, r = 0;
+      for (int i = 0; i < n; i++) {
+        const uint32_t sym = AnsSym<true>(b, state, abase, tab.log_alpha);
+        resid[r * 256 + x] = (int32_t)((uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * leaf.b + (uint32_t)leaf.splitval);
+        if (++x == w) { x = 0; r++; }
+      }
+    }
+    __syncthreads();
+    {
+      const int y = y0 + lane;
+      const bool row_active = lane < nrows;
+      int32_t W = 0, N = 0, NW = 0, val = 0;
+      const int steps = w + nrows - 1;
+      for (int t = 0; t < steps; t++) {
+        const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
+        const int x = t - lane;
+        if (row_active && x >= 0 && x < w) {
+          int32_t n_in;
+          if (lane == 0) n_in = y ? rb[x] : 0;
+          else n_in = from_up;
+          if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
+          else if (y) { NW = N; N = n_in; }
+          else { NW = W; N = W; }
+          uint32_t guess;
+          if (pred == 0) guess = 0;
+          else if (pred == 1) guess = (uint32_t)W;
+          else if (pred == 2) guess = (uint32_t)N;
+          else {
+            const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
+            guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
+          }
+          const uint32_t res = constant_token ? const_res : (uint32_t)resid[lane * 256 + x];
+          val = (int32_t)(res + guess);
+          out[(size_t)y * stride + x] = val;
+          if (lane == nrows - 1) rb[x] = val;
+          W = val;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // If channel `chan` of stream `stream_id` resolves (on static properties only) to a leaf with the Zero
 // predictor whose cluster is degenerate (one symbol, no extra bits), every sample equals a constant that
 // can be written without touching the stream.  Returns true and the constant.
@@ -380,16 +457,19 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   extern __shared__ __align__(16) uint8_t smem[];
   __shared__ uint32_t s_err;
   __shared__ uint32_t s_count;
+  __shared__ uint32_t s_cov[256 * 8];   // coverage bitmap of the LF group's 256 x 256 cells
   const DevImage& im = imgs[tasks[blockIdx.x].image];
   const int g = tasks[blockIdx.x].first;
   const int tid = threadIdx.x;
   CodeTab<kLds> tab;
   typename AS<kLds>::Tree tree;
   RowBuf<kLds> rbuf;
+  JXL_LDS int32_t* resid = nullptr;
   if constexpr (kLds) {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     size_t off = 0;
     rbuf.rb = (JXL_LDS int32_t*)lds; off += 256 * 4;
+    resid = (JXL_LDS int32_t*)(lds + off); off += 64 * 256 * 4;
     JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
     for (int i = tid; i < im.tree_size; i += 64) st[i] = ((const I4*)im.tree)[i];
     tree = st;
@@ -413,37 +493,47 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   int32_t* s_info = scratch + 2048;
   int32_t* s_sharp = scratch + 2048 + 2 * 65536;
   const int sid_meta = 1 + 2 * im.nlf + g;
-  // channels whose value is a stream-independent constant are filled by the whole wavefront
-  int32_t cval[4];
-  bool cconst[4];
-  for (int mc = 0; mc < 4; mc++) cconst[mc] = ConstantChannel(tab, tree, mc, sid_meta, &cval[mc]);
   LaneBits b;
   uint32_t state = 0;
+  // Decodes one channel: wavefront split-phase when the stream allows it, else serially on lane 0.
+  auto channel = [&](int chan, int sid, int w, int h, int32_t* out, int stride) {
+    DevTreeNode leaf;
+    bool wave = false;
+    if constexpr (kLds) {
+      if (w <= 256 && StaticLeaf<kLds>(tree, chan, sid, &leaf)) {
+        const uint32_t p = leaf.a & 0xFF;
+        wave = p == 0 || p == 1 || p == 2 || p == 5;
+      }
+      if (wave) {
+        ModularChannelWave(b, state, tab, leaf, w, h, out, stride, rbuf.rb, resid, tid);
+        return;
+      }
+    }
+    if (tid == 0) ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out, stride, rbuf);
+    __syncthreads();
+  };
   if (tid == 0) {
     uint32_t err = 0;
     b.Init(im.cs, im.cs_size, im.sec_off[1 + g] * 8);
     im.lf_extra[g] = (uint8_t)b.Read(2);
     if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
-    if (!err) {
-      state = b.Read(32);
-      const int chan_of[3] = {1, 0, 2};
-      for (int mc = 0; mc < 3; mc++)
-        ModularChannel(b, state, tab, tree, mc, 1 + g, bw, bh, im.lfq[chan_of[mc]] + (size_t)by0 * im.w8 + bx0, im.w8, rbuf);
-      if (state != 0x130000u) err |= kErrBitstream;
-    }
-    uint32_t count = 1;
+    state = b.Read(32);
+    s_err = err;
+  }
+  __syncthreads();
+  if (s_err) { if (tid == 0) SetError(im, s_err); return; }
+  {
+    const int chan_of[3] = {1, 0, 2};
+    for (int mc = 0; mc < 3; mc++) channel(mc, 1 + g, bw, bh, im.lfq[chan_of[mc]] + (size_t)by0 * im.w8 + bx0, im.w8);
+  }
+  if (tid == 0) {
+    uint32_t err = 0, count = 1;
+    if (state != 0x130000u) err |= kErrBitstream;
     if (!err) {
       count = b.Read(CeilLog2D((uint32_t)(bw * bh))) + 1;
       if (count > (uint32_t)(bw * bh)) err |= kErrBlockLayout;
       else if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
-    }
-    if (!err) {
       state = b.Read(32);
-      if (!cconst[0]) ModularChannel(b, state, tab, tree, 0, sid_meta, tw, th, s_x, tw, rbuf);
-      if (!cconst[1]) ModularChannel(b, state, tab, tree, 1, sid_meta, tw, th, s_b, tw, rbuf);
-      if (!cconst[2]) ModularChannel(b, state, tab, tree, 2, sid_meta, (int)count, 2, s_info, (int)count, rbuf);
-      if (!cconst[3]) ModularChannel(b, state, tab, tree, 3, sid_meta, bw, bh, s_sharp, bw, rbuf);
-      if (state != 0x130000u || b.Consumed() > (uint64_t)im.sec_size[1 + g] * 8) err |= kErrBitstream;
     }
     s_err = err;
     s_count = count;
@@ -451,11 +541,25 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   __syncthreads();
   if (s_err) { if (tid == 0) SetError(im, s_err); return; }
   const uint32_t count = s_count;
-  if (cconst[0]) for (int i = tid; i < tw * th; i += 64) s_x[i] = cval[0];
-  if (cconst[1]) for (int i = tid; i < tw * th; i += 64) s_b[i] = cval[1];
-  if (cconst[2]) for (uint32_t i = tid; i < 2 * count; i += 64) s_info[i] = cval[2];
-  if (cconst[3]) for (int i = tid; i < bw * bh; i += 64) s_sharp[i] = cval[3];
+  {
+    // channels whose value is a stream-independent constant are filled by the whole wavefront
+    int32_t cval;
+    if (ConstantChannel<kLds>(tab, tree, 0, sid_meta, &cval)) { for (int i = tid; i < tw * th; i += 64) s_x[i] = cval; }
+    else channel(0, sid_meta, tw, th, s_x, tw);
+    if (ConstantChannel<kLds>(tab, tree, 1, sid_meta, &cval)) { for (int i = tid; i < tw * th; i += 64) s_b[i] = cval; }
+    else channel(1, sid_meta, tw, th, s_b, tw);
+    if (ConstantChannel<kLds>(tab, tree, 2, sid_meta, &cval)) { for (uint32_t i = tid; i < 2 * count; i += 64) s_info[i] = cval; }
+    else channel(2, sid_meta, (int)count, 2, s_info, (int)count);
+    if (ConstantChannel<kLds>(tab, tree, 3, sid_meta, &cval)) { for (int i = tid; i < bw * bh; i += 64) s_sharp[i] = cval; }
+    else channel(3, sid_meta, bw, bh, s_sharp, bw);
+  }
+  if (tid == 0) {
+    uint32_t err = 0;
+    if (state != 0x130000u || b.Consumed() > (uint64_t)im.sec_size[1 + g] * 8) err |= kErrBitstream;
+    s_err = err;
+  }
   __syncthreads();
+  if (s_err) { if (tid == 0) SetError(im, s_err); return; }
   // chroma-from-luma maps and sharpness: parallel copies with range checks
   uint32_t err = 0;
   const int tx0 = bx0 / 8, ty0 = by0 / 8;
@@ -472,29 +576,58 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
     if (sh < 0 || sh > 7) { err |= kErrRange; sh = 0; }
     im.sharp[(size_t)(by0 + y) * im.w8 + bx0 + x] = (uint8_t)sh;
   }
-  // varblock placement: raster scan, each block info entry goes to the first uncovered cell (serial by definition)
+  __syncthreads();   // s_sharp has been consumed: its scratch is reused for the block positions
+  // ---- varblock placement.  By definition serial (each entry goes to the first cell, in raster order, not yet covered),
+  // but only per BLOCK: lane 0 walks a coverage bitmap in LDS (one 32-bit word per 32 cells) and records positions; the
+  // per-cell fan-out (cellinfo / raw quant of every covered cell) is then done by all lanes.
+  int32_t* s_pos = s_sharp;
+  if (tid == 0) s_count = 0;
+  for (int i = tid; i < 256 * 8; i += 64) s_cov[i] = 0;
+  __syncthreads();
   if (tid == 0) {
     uint32_t num = 0;
-    for (int y = 0; y < bh; y++)
-      for (int x = 0; x < bw; x++) {
-        const size_t cell = (size_t)(by0 + y) * im.w8 + bx0 + x;
-        if (im.cellinfo[cell] >> 31) continue;
-        if (num >= count) { err |= kErrBlockLayout; continue; }
-        const int s = s_info[num];
-        const int q = 1 + s_info[count + num];
-        num++;
-        if (s < 0 || s >= kNumStrategies || q < 1 || q > 256) { err |= kErrBlockLayout; continue; }
-        const int lcx = d_log2cx[s], lcy = d_log2cy[s], cx = 1 << lcx, cy = 1 << lcy;
-        if (x + cx > bw || y + cy > bh || (x & 31) + cx > 32 || (y & 31) + cy > 32) { err |= kErrBlockLayout; continue; }
-        for (int iy = 0; iy < cy; iy++)
-          for (int ix = 0; ix < cx; ix++) {
-            const size_t cc = cell + (size_t)iy * im.w8 + ix;
-            if (im.cellinfo[cc] >> 31) err |= kErrBlockLayout;
-            im.cellinfo[cc] = (uint32_t)s | ix << 8 | iy << 13 | lcx << 18 | lcy << 21 | 1u << 31;
-            im.rawq[cc] = (uint16_t)q;
-          }
+    const int words = (bw + 31) >> 5;
+    for (int y = 0; y < bh && !(err & kErrBlockLayout); y++) {
+      for (int wi = 0; wi < words; wi++) {
+        for (;;) {
+          uint32_t freebits = ~s_cov[y * 8 + wi];
+          const int lim = min(32, bw - wi * 32);
+          if (lim < 32) freebits &= (1u << lim) - 1;
+          if (!freebits) break;
+          const int xb = __ffs(freebits) - 1;
+          const int x = wi * 32 + xb;
+          if (num >= count) { err |= kErrBlockLayout; break; }
+          const int s = s_info[num];
+          const int q = 1 + s_info[count + num];
+          if (s < 0 || s >= kNumStrategies || q < 1 || q > 256) { err |= kErrBlockLayout; break; }
+          const int lcx = d_log2cx[s], lcy = d_log2cy[s], cx = 1 << lcx, cy = 1 << lcy;
+          if (x + cx > bw || y + cy > bh || xb + cx > 32 || (y & 31) + cy > 32) { err |= kErrBlockLayout; break; }
+          const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1)) << xb;
+          uint32_t clash = 0;
+          for (int iy = 0; iy < cy; iy++) { clash |= s_cov[(y + iy) * 8 + wi] & mask; s_cov[(y + iy) * 8 + wi] |= mask; }
+          if (clash) { err |= kErrBlockLayout; break; }
+          s_pos[num] = x | y << 8;
+          num++;
+        }
+        if (err & kErrBlockLayout) break;
       }
+    }
     if (num != count) err |= kErrBlockLayout;
+    s_count = num;
+  }
+  __syncthreads();
+  const uint32_t placed = s_count;
+  for (uint32_t i = tid; i < placed; i += 64) {
+    const int x = s_pos[i] & 0xFF, y = s_pos[i] >> 8;
+    const int s = s_info[i], q = 1 + s_info[count + i];
+    const int lcx = d_log2cx[s], lcy = d_log2cy[s], cx = 1 << lcx, cy = 1 << lcy;
+    const size_t cell = (size_t)(by0 + y) * im.w8 + bx0 + x;
+    for (int iy = 0; iy < cy; iy++)
+      for (int ix = 0; ix < cx; ix++) {
+        const size_t cc = cell + (size_t)iy * im.w8 + ix;
+        im.cellinfo[cc] = (uint32_t)s | ix << 8 | iy << 13 | lcx << 18 | lcy << 21 | 1u << 31;
+        im.rawq[cc] = (uint16_t)q;
+      }
   }
   if (err) SetError(im, err);
 }
@@ -658,6 +791,7 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
   CodeTab<kLds> tab;
   typename AS<kLds>::Tree tree;
   RowBuf<kLds> rbuf;
+  JXL_LDS int32_t* resid = nullptr;
   const int slots = 64 / lane_stride;
   if constexpr (kLds) {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
@@ -665,6 +799,7 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
     rbuf.rb = (JXL_LDS int32_t*)lds + threadIdx.x / lane_stride; off += (size_t)slots * 256 * 4;
     rbuf.rb_stride = slots;
     rbuf.rb_width = 256;
+    if (lane_stride == 64) { resid = (JXL_LDS int32_t*)(lds + off); off += 64 * 256 * 4; }
     JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
     for (int i = threadIdx.x; i < im.tree_size; i += 64) st[i] = ((const I4*)im.tree)[i];
     tree = st;
@@ -674,6 +809,45 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
     GlobalCode(im.mcode, tab);
     tree = (const I4*)im.tree;
     rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
+  }
+  if constexpr (kLds) {
+    if (lane_stride == 64) {
+      // one section per wavefront: split-phase decode by all 64 lanes when the stream allows it
+      __shared__ uint32_t s_fail;
+      const int g = task.first;
+      const uint64_t start = im.grp_bitpos[g];
+      if (start == ~(uint64_t)0) return;
+      const int gx = g % im.xg, gy = g / im.xg;
+      const int sec = 2 + im.nlf + g;
+      const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
+      const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
+      const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
+      DevTreeNode leaf;
+      bool wave = StaticLeaf<true>(tree, 0, sid, &leaf);
+      if (wave) { const uint32_t p = leaf.a & 0xFF; wave = p == 0 || p == 1 || p == 2 || p == 5; }
+      LaneBits b;
+      uint32_t state = 0;
+      if (threadIdx.x == 0) {
+        b.Init(im.cs, im.cs_size, start);
+        s_fail = b.Read(4) != 3 ? (uint32_t)kErrUnsupportedHeader : 0u;
+        state = b.Read(32);
+      }
+      __syncthreads();
+      if (s_fail) { if (threadIdx.x == 0) SetError(im, s_fail); return; }
+      int32_t* out = im.alpha32 + (size_t)y0 * im.w + x0;
+      if (wave) {
+        ModularChannelWave(b, state, tab, leaf, gw, gh, out, im.w, (JXL_LDS int32_t*)smem, resid, threadIdx.x);
+      } else if (threadIdx.x == 0) {
+        ModularChannel<true>(b, state, tab, tree, 0, sid, gw, gh, out, im.w, rbuf);
+      }
+      if (threadIdx.x == 0) {
+        uint32_t err = 0;
+        if (state != 0x130000u) err |= kErrBitstream;
+        if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
+        if (err) SetError(im, err);
+      }
+      return;
+    }
   }
   if (threadIdx.x % lane_stride) return;
   const int si = threadIdx.x / lane_stride;

@@ -13,8 +13,12 @@ void LaunchAlpha(const DevImage* imgs, const SectionTask* tasks, int nwg, int la
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
 void LaunchAlphaToU8(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
-void LaunchReconstruct(const DevImage* imgs, int nimg, size_t max_padded_pixels, size_t max_cells, const float* basis_all,
-                       const float* basis_small, const float* llf_scale, hipStream_t s);
-void LaunchFiltersAndOutput(const DevImage* imgs, int nimg, size_t max_pixels, bool any_gab, int max_epf, hipStream_t s);
+void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,
+                              const float* llf_scale, hipStream_t s);
+// tile_kernels.hip
+void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
+                      const float* llf_scale, hipStream_t s);
+void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
+                       hipStream_t s);
 
 }  // namespace jxlhip

@@ -1,0 +1,410 @@
+// LDS-tiled pixel stages (gfx950).
+//
+//   recon_tile_kernel    one workgroup per 64x64 tile: dequantisation (+ chroma from luma), LF->LLF, both IDCT passes
+//                        all in LDS (tiles with special 8x8 transforms or blocks > 64 go to the generic kernels).  HBM traffic: 12 B/px in (int32 coefficients),
+//                        12 B/px out (f32 XYB).  Tiles that hold part of a varblock larger than the tile are appended to a
+//                        per-image list and handled by the generic (unfused, any-size) kernels of kernels.hip.
+//   filter_tile_kernel   Gaborish / EPF stage on a 64x32 tile + halo staged in LDS (mirrored at the frame edge exactly like
+//                        the unfused stage).  The LAST enabled stage of an image converts XYB -> sRGB u8 and merges alpha
+//                        instead of writing float planes.
+#include <hip/hip_runtime.h>
+#include <cstdlib>
+#include "dev_types.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+namespace {
+
+constexpr int kTS = 64;       // tile side
+constexpr int kLP = 65;       // LDS pitch (conflict-free column walks)
+
+__device__ const uint8_t t_quant_table[kNumStrategies] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+
+__device__ __forceinline__ bool Special(uint32_t s) { return (s >= 1 && s <= 3) || (s >= 12 && s <= 17); }
+__device__ __forceinline__ int Mirror(int v, int n) {
+  while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
+  return v;
+}
+
+__device__ __forceinline__ float SrgbOetfT(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f; }
+__device__ __forceinline__ uint8_t ToU8T(float v) {
+  v *= 255.0f;
+  if (!(v > 0.f)) return 0;
+  if (v >= 255.0f) return 255;
+  return (uint8_t)(v + 0.5f);
+}
+
+__device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, float X, float Y, float B) {
+  const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
+  const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
+  float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
+  float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
+  float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
+  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
+  const size_t i = (size_t)y * im.w + x;
+  if (im.nch_out == 4) {
+    uchar4 px;
+    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = im.alpha[i];
+    ((uchar4*)im.out)[i] = px;
+  } else {
+    uint8_t* out = im.out + i * im.nch_out;
+    if (im.ncolor == 3) {
+      out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
+    } else {
+      out[0] = ToU8T(g);
+      if (im.has_alpha) out[1] = im.alpha[i];
+    }
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ fused reconstruction of one 64x64 tile
+// One channel at a time (Y, X, B); the chroma-from-luma term re-derives the dequantised Y coefficient from the
+// quantised Y plane instead of keeping three coefficient tiles resident, so that the IDCT bases of every size
+// up to 64 fit in LDS next to the tile (2 workgroups per CU).
+constexpr int kBasisFloats = 5440;   // N = 8,16,32,64 at offsets (N*N-64)/3
+// kBasisLds: keep the IDCT bases in LDS (2 workgroups/CU) or read them through L1 (4 workgroups/CU)
+template <bool kBasisLds>
+__global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
+                                                         const float* llf_scale, int ablate) {
+  extern __shared__ __align__(16) uint8_t smem_raw[];
+  float* cfc = (float*)smem_raw;               // kTS * kLP   coefficients, then pixels, of the current channel
+  float* tmpb = cfc + kTS * kLP;               // kTS * kLP   after the vertical pass
+  float* Bl_lds = tmpb + kTS * kLP;            // kBasisFloats (only when kBasisLds)
+  uint32_t* ci = (uint32_t*)(Bl_lds + (kBasisLds ? kBasisFloats : 0));   // 64
+  uint32_t* rq = ci + 64;                      // 64
+  float* lft = (float*)(rq + 64);              // 64   LF samples of the tile / horizontally transformed
+  float* Bs = lft + 64;                        // 85   small DCT bases, c = 1,2,4,8 at offsets (c*c-1)/3
+  float* cscale = Bs + 96;                     // 64   per cell: inv_global_scale / raw quant of its varblock
+  const float** cw = (const float**)(cscale + 64);   // 64   per cell: dequant table base
+  uint32_t* cnq = (uint32_t*)(cw + 64);        // 64   per cell: entries per channel in that table
+  const DevImage& im = imgs[blockIdx.y];
+  const int tile = blockIdx.x;
+  if (tile >= im.wt * im.ht) return;
+  if (ablate & 16) return;
+  const int tid = threadIdx.x;
+  const int tx = tile % im.wt, ty = tile / im.wt;
+  int bad = 0;
+  if (tid < 64) {
+    const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
+    const bool inside = cx < im.w8 && cy < im.h8;
+    const uint32_t info = inside ? im.cellinfo[(size_t)cy * im.w8 + cx] : 0u;
+    ci[tid] = info;
+    rq[tid] = inside ? im.rawq[(size_t)cy * im.w8 + cx] : 1u;
+    if (inside) {
+      if (!(info >> 31)) bad = 1;
+      else {
+        const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+        const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
+        // blocks larger than the tile, and the rare special 8x8 transforms, are left to the generic kernels
+        bad = ox < 0 || oy < 0 || ox + (1 << lcx) > 8 || oy + (1 << lcy) > 8 || Special(info & 0xFF);
+      }
+    }
+  }
+  if (__syncthreads_or(bad)) {
+    if (tid == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
+    return;
+  }
+  const float* Bl = basis_all;
+  if constexpr (kBasisLds) {
+    for (int i = tid; i < kBasisFloats; i += 256) Bl_lds[i] = basis_all[i];
+    Bl = Bl_lds;
+  }
+  if (tid < 85) Bs[tid] = basis_small[tid];
+  if (tid < 64) {
+    const uint32_t info = ci[tid];
+    const uint32_t q = t_quant_table[info & 0xFF];
+    const int ix = (info >> 8) & 31, iy = (info >> 13) & 31;
+    cscale[tid] = im.inv_global_scale / (float)rq[(info >> 31) ? tid - iy * 8 - ix : tid];
+    cw[tid] = im.dq[q];
+    cnq[tid] = im.dq_n[q];
+  }
+  __syncthreads();
+  if (ablate & 32) return;
+  const size_t tile_cfl = (size_t)ty * im.wt + tx;
+  const float cfx = im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor;
+  const float cfb = im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor;
+  const float qb0 = im.qbias[0], qb1 = im.qbias[1], qb2 = im.qbias[2], qb3 = im.qbias[3];
+  const int wp = im.wp, hp = im.hp;
+#pragma unroll 1
+  for (int cidx = 0; cidx < 3; cidx++) {
+    const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
+    const float qbc = c == 0 ? qb0 : (c == 1 ? qb1 : qb2);
+    const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
+    const float cfl = c == 0 ? cfx : (c == 1 ? 0.f : cfb);
+    const int32_t* qc = im.coef[c];
+    const int32_t* qy = im.coef[1];
+    // ---- dequantisation (+ chroma from luma).  Fully unrolled with unconditional (clamped) loads so that the 16
+    // coefficient / weight fetches of a thread are in flight together instead of one round trip per element.
+#pragma unroll 2
+    for (int it = 0; it < 16; it++) {
+      const int e = tid + it * 256;
+      const int y = e >> 6, x = e & 63;
+      const int gx = tx * kTS + x, gy = ty * kTS + y;
+      const bool inside = gx < wp && gy < hp;
+      const int cell = (y >> 3) * 8 + (x >> 3);
+      const uint32_t info = ci[cell];
+      const uint32_t s = info & 0xFF, ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+      const int kx = (x & 7) + 8 * ix, ky = (y & 7) + 8 * iy;
+      const uint32_t lng_log2 = 3 + max(lcx, lcy);
+      // square DCT tables are symmetric: index them row-major so that consecutive lanes read consecutive weights
+      const bool transposed = !Special(s) && lcy > lcx;
+      const uint32_t idx = inside ? (transposed ? ((uint32_t)kx << lng_log2) + ky : ((uint32_t)ky << lng_log2) + kx) : 0u;
+      const float* wt = cw[cell];
+      const uint32_t nq = cnq[cell];
+      const float scale = cscale[cell];
+      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 1);
+      const int32_t v = (ablate & 1) ? (int32_t)idx : qc[g];
+      const float wv = (ablate & 1) ? scale : wt[(size_t)c * nq + idx];
+      float a;
+      if (v == 0) a = 0.f;
+      else if (v == 1) a = qbc;
+      else if (v == -1) a = -qbc;
+      else a = (float)v - qb3 / (float)v;
+      float o = a * (scale * dm) * wv;
+      if (c != 1) {
+        const int32_t vy = (ablate & 1) ? (int32_t)idx : qy[g];
+        const float wy = (ablate & 1) ? scale : wt[(size_t)nq + idx];
+        float ay;
+        if (vy == 0) ay = 0.f;
+        else if (vy == 1) ay = qb1;
+        else if (vy == -1) ay = -qb1;
+        else ay = (float)vy - qb3 / (float)vy;
+        o += cfl * (ay * scale * wy);
+      }
+      cfc[y * kLP + x] = inside ? o : 0.f;
+    }
+    __syncthreads();
+    // ---- LLF: lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples (separable, all in LDS)
+    if (tid < 64) {
+      const int cx8 = tx * 8 + (tid & 7), cy8 = ty * 8 + (tid >> 3);
+      lft[tid] = (cx8 < im.w8 && cy8 < im.h8) ? im.lf_final[c][(size_t)cy8 * im.w8 + cx8] : 0.f;
+    }
+    __syncthreads();
+    float llf_row = 0.f;
+    if (tid < 64 && !(ablate & 8)) {
+      const uint32_t info = ci[tid];
+      if (info >> 31) {
+        const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
+        const int cx = 1 << lcx;
+        const float* Bx = Bs + (cx * cx - 1) / 3 + ix * cx;
+        const float* lf = lft + (tid >> 3) * 8 + (tid & 7) - ix;
+        for (int x = 0; x < cx; x++) llf_row += lf[x] * Bx[x];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) lft[tid] = llf_row;   // lft[y][kx]: horizontally transformed
+    __syncthreads();
+    if (tid < 64) {
+      const uint32_t info = ci[tid];
+      if (info >> 31) {
+        const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+        const int cx = 1 << lcx, cy = 1 << lcy;
+        const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
+        const float* By = Bs + (cy * cy - 1) / 3 + iy * cy;
+        float acc = 0.f;
+        for (int y = 0; y < cy; y++) acc += lft[(oy + y) * 8 + ox + ix] * By[y];
+        const float sc = llf_scale[lcy * 32 + iy] * llf_scale[lcx * 32 + ix] / (float)(cx * cy);
+        cfc[(oy * 8 + iy) * kLP + ox * 8 + ix] = acc * sc;
+      }
+    }
+    __syncthreads();
+    // ---- vertical pass -> tmpb.  One thread = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
+    if (!(ablate & 2)) {
+      const int x = (tid & 31) * 2, cr = tid >> 5;
+      const uint32_t info = ci[cr * 8 + (x >> 3)];
+      if (info >> 31) {
+        const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
+        const int R = 8 << lcy;
+        const float* B = Bl + (R * R - 64) / 3 + iy * 8;
+        const float* in = cfc + (cr - iy) * 8 * kLP + x;
+        float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < R; k++) {
+          const float v0 = in[k * kLP], v1 = in[k * kLP + 1];
+          const float4 b0 = *(const float4*)(B + k * R);
+          const float4 b1 = *(const float4*)(B + k * R + 4);
+          a0[0] += v0 * b0.x; a0[1] += v0 * b0.y; a0[2] += v0 * b0.z; a0[3] += v0 * b0.w;
+          a0[4] += v0 * b1.x; a0[5] += v0 * b1.y; a0[6] += v0 * b1.z; a0[7] += v0 * b1.w;
+          a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;
+          a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { tmpb[(cr * 8 + j) * kLP + x] = a0[j]; tmpb[(cr * 8 + j) * kLP + x + 1] = a1[j]; }
+      }
+    }
+    __syncthreads();
+    // ---- horizontal pass: tmpb -> cfc (the coefficients of this channel are dead now).  Two adjacent rows per thread.
+    if (!(ablate & 2)) {
+      const int y = (tid & 31) * 2, cc = tid >> 5;
+      const uint32_t info = ci[(y >> 3) * 8 + cc];
+      if (info >> 31) {
+        const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
+        const int C = 8 << lcx;
+        const float* B = Bl + (C * C - 64) / 3 + ix * 8;
+        const float* in = tmpb + y * kLP + (cc - ix) * 8;
+        float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < C; k++) {
+          const float v0 = in[k], v1 = in[k + kLP];
+          const float4 b0 = *(const float4*)(B + k * C);
+          const float4 b1 = *(const float4*)(B + k * C + 4);
+          a0[0] += v0 * b0.x; a0[1] += v0 * b0.y; a0[2] += v0 * b0.z; a0[3] += v0 * b0.w;
+          a0[4] += v0 * b1.x; a0[5] += v0 * b1.y; a0[6] += v0 * b1.z; a0[7] += v0 * b1.w;
+          a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;
+          a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { cfc[y * kLP + cc * 8 + j] = a0[j]; cfc[(y + 1) * kLP + cc * 8 + j] = a1[j]; }
+      }
+    }
+    __syncthreads();
+    // ---- coalesced copy-out of this channel
+    float* dst = im.xyb[c];
+#pragma unroll
+    for (int it = 0; it < 16; it++) {
+      const int e = tid + it * 256;
+      const int y = e >> 6, x = e & 63;
+      const int gx = tx * kTS + x, gy = ty * kTS + y;
+      if (gx < wp && gy < hp && !(ablate & 4)) dst[(size_t)gy * wp + gx] = cfc[y * kLP + x];
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ LDS-tiled loop filters
+// kStage: 0 Gaborish, 1 EPF pass 0, 2 EPF pass 1, 3 EPF pass 2.  Tile = 64 x 32 output pixels.
+template <int kStage>
+__global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) {
+  constexpr int TW = 64, TH = 32;
+  constexpr int HALO = kStage == 0 ? 1 : (kStage == 1 ? 3 : (kStage == 2 ? 2 : 1));
+  constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
+  __shared__ float t[3][LH][LW + 1];
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.stage_on[kStage]) return;
+  const int w = im.w, h = im.h, wp = im.wp;
+  const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const float* in0 = im.stage_in[kStage][0];
+  const float* in1 = im.stage_in[kStage][1];
+  const float* in2 = im.stage_in[kStage][2];
+  for (int e = threadIdx.x; e < LW * LH; e += 256) {
+    const int ly = e / LW, lx = e % LW;
+    const size_t g = (size_t)Mirror(y0 - HALO + ly, h) * wp + Mirror(x0 - HALO + lx, w);
+    t[0][ly][lx] = in0[g];
+    t[1][ly][lx] = in1[g];
+    t[2][ly][lx] = in2[g];
+  }
+  __syncthreads();
+  const bool final_stage = im.final_stage == kStage;
+  for (int e = threadIdx.x; e < TW * TH; e += 256) {
+    const int ly = e / TW, lx = e % TW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y >= h) continue;
+    const int cy = ly + HALO, cx = lx + HALO;
+    float o0, o1, o2;
+    if (kStage == 0) {
+      float o[3];
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        o[c] = t[c][cy][cx] * im.gab_w[c][0] +
+               (t[c][cy - 1][cx] + t[c][cy + 1][cx] + t[c][cy][cx - 1] + t[c][cy][cx + 1]) * im.gab_w[c][1] +
+               (t[c][cy - 1][cx - 1] + t[c][cy - 1][cx + 1] + t[c][cy + 1][cx - 1] + t[c][cy + 1][cx + 1]) * im.gab_w[c][2];
+      }
+      o0 = o[0]; o1 = o[1]; o2 = o[2];
+    } else {
+      constexpr int kNoff = kStage == 1 ? 12 : 4;
+      constexpr int kNplus = kStage == 3 ? 1 : 5;
+      const int off0[12][2] = {{-2, 0}, {-1, -1}, {-1, 0}, {-1, 1}, {0, -2}, {0, -1}, {0, 1}, {0, 2}, {1, -1}, {1, 0}, {1, 1}, {2, 0}};
+      const int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+      const int plus[5][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}};
+      const float is = im.inv_sigma[(size_t)(y >> 3) * im.w8 + (x >> 3)];
+      o0 = t[0][cy][cx]; o1 = t[1][cy][cx]; o2 = t[2][cy][cx];
+      if (!(is < -3.90524291751269967465540850526868f)) {
+        const float sm = kStage == 1 ? im.epf_pass0_sigma_scale : (kStage == 2 ? 1.0f : im.epf_pass2_sigma_scale);
+        const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
+        const float inv = is * (border ? sm * im.epf_border_sad_mul : sm);
+        float wsum = 1.0f;
+#pragma unroll
+        for (int k = 0; k < kNoff; k++) {
+          const int dy = kStage == 1 ? off0[k][0] : off1[k][0], dx = kStage == 1 ? off0[k][1] : off1[k][1];
+          float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int p = 0; p < kNplus; p++) {
+            const int ay = cy + plus[p][0], ax = cx + plus[p][1];
+            s0 += fabsf(t[0][ay][ax] - t[0][ay + dy][ax + dx]);
+            s1 += fabsf(t[1][ay][ax] - t[1][ay + dy][ax + dx]);
+            s2 += fabsf(t[2][ay][ax] - t[2][ay + dy][ax + dx]);
+          }
+          const float sad = s0 * im.epf_channel_scale[0] + s1 * im.epf_channel_scale[1] + s2 * im.epf_channel_scale[2];
+          const float wt = fmaxf(0.0f, 1.0f + sad * inv);
+          wsum += wt;
+          o0 += wt * t[0][cy + dy][cx + dx];
+          o1 += wt * t[1][cy + dy][cx + dx];
+          o2 += wt * t[2][cy + dy][cx + dx];
+        }
+        const float iw = 1.0f / wsum;
+        o0 *= iw; o1 *= iw; o2 *= iw;
+      }
+    }
+    if (final_stage) {
+      WritePixel(im, x, y, o0, o1, o2);
+    } else {
+      const size_t g = (size_t)y * wp + x;
+      im.stage_out[kStage][0][g] = o0;
+      im.stage_out[kStage][1][g] = o1;
+      im.stage_out[kStage][2][g] = o2;
+    }
+  }
+}
+
+// no loop filter at all: plain conversion
+__global__ void out_only_kernel(const DevImage* imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (im.final_stage != 4) return;
+  const int w = im.w, wp = im.wp;
+  const size_t n = (size_t)w * im.h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % w), y = (int)(i / w);
+    const size_t o = (size_t)y * wp + x;
+    WritePixel(im, x, y, im.stage_in[4][0][o], im.stage_in[4][1][o], im.stage_in[4][2][o]);
+  }
+}
+
+void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
+                      const float* llf_scale, hipStream_t s) {
+  static const bool basis_lds = getenv("JXLHIP_RECON_BASIS_LDS") != nullptr;
+  const size_t extra = (128 + 64 + 96 + 64 + 128 + 64) * 4;
+  if (basis_lds) {
+    const size_t lds = (size_t)(2 * kTS * kLP + kBasisFloats) * 4 + extra;
+    static bool raised = false;
+    if (!raised) {
+      (void)hipFuncSetAttribute((const void*)recon_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      raised = true;
+    }
+    hipLaunchKernelGGL(recon_tile_kernel<true>, dim3(max_tiles, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
+  } else {
+    size_t lds = (size_t)(2 * kTS * kLP) * 4 + extra;
+    if (getenv("JXLHIP_RECON_LDS")) lds = (size_t)atoi(getenv("JXLHIP_RECON_LDS"));
+    hipLaunchKernelGGL(recon_tile_kernel<false>, dim3(max_tiles, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
+  }
+}
+
+void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
+                       hipStream_t s) {
+  const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
+  dim3 g(tiles, nimg);
+  if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
+  if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);
+  if (max_epf >= 1) hipLaunchKernelGGL(filter_tile_kernel<2>, g, dim3(256), 0, s, imgs);
+  if (max_epf >= 2) hipLaunchKernelGGL(filter_tile_kernel<3>, g, dim3(256), 0, s, imgs);
+  if (any_unfiltered) {
+    size_t work = (size_t)max_w * max_h;
+    size_t b = std::min<size_t>((work + 255) / 256, 8192);
+    hipLaunchKernelGGL(out_only_kernel, dim3((unsigned)b, nimg), dim3(256), 0, s, imgs);
+  }
+}
+
+}  // namespace jxlhip

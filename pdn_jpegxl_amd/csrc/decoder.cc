@@ -76,8 +76,9 @@ struct JxlHipDecoder {
   uint16_t* d_natural[kNumOrders] = {};
   float* d_dq[kNumQuantTables] = {};
   uint32_t dq_n[kNumQuantTables] = {};
-  // Per-batch state lives in one of two slots so that the LF stage of batch k+1 (stream_lf) overlaps the HF and pixel
-  // stages of batch k (main stream) when the caller does not synchronise between batches.
+  // Per-batch state lives in one of three slots so that, when the caller does not synchronise between batches, the LF
+  // stage of batch k+2 (stream_lf), the HF-coefficient stage of batch k+1 (stream_hf) and the alpha + pixel stages of
+  // batch k (main stream) run concurrently: the serial entropy kernels leave most issue slots of the chip idle.
   struct Tap { std::vector<uint8_t> qcoef[3], xyb_idct[3], xyb_filtered[3]; };
   struct Slot {
     // grow-only buffers
@@ -93,7 +94,7 @@ struct JxlHipDecoder {
     std::vector<size_t> status_off;      // offset of each image's status words in the workspace
     DevImage* d_imgs = nullptr;
     bool pending = false;
-    hipEvent_t lf_done = nullptr, done = nullptr;
+    hipEvent_t lf_done = nullptr, hf_done = nullptr, done = nullptr;
     std::vector<Tap> taps;
     // timing: two event chains (LF stream, main stream)
     std::vector<std::string> stage_names;
@@ -101,10 +102,12 @@ struct JxlHipDecoder {
     std::vector<hipEvent_t> events;
     std::vector<float> stage_ms;
   };
-  Slot slots[2];
+  static constexpr int kSlots = 3;
+  Slot slots[kSlots];
   int cur = 0, last = 0;
   Slot* active = &slots[0];
   hipStream_t stream_lf = nullptr;
+  hipStream_t stream_hf = nullptr;
   hipStream_t last_stream = nullptr;
   // cumulative per-stage HIP-event time over every finished batch since the last reset (bench: timed region)
   std::vector<std::string> total_names;
@@ -136,8 +139,10 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   HIP_OK(hipSetDevice(device));
   HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
   HIP_OK(hipStreamCreateWithFlags(&stream_lf, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&stream_hf, hipStreamNonBlocking));
   for (auto& S : slots) {
     HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
   }
   if (const char* e = getenv("JXLHIP_NO_OVERLAP")) overlap = atoi(e) == 0;
@@ -178,6 +183,7 @@ JxlHipDecoder::~JxlHipDecoder() {
   for (auto& S : slots) {
     for (auto e : S.events) (void)hipEventDestroy(e);
     if (S.lf_done) (void)hipEventDestroy(S.lf_done);
+    if (S.hf_done) (void)hipEventDestroy(S.hf_done);
     if (S.done) (void)hipEventDestroy(S.done);
     (void)hipFree(S.d_ws); (void)hipFree(S.d_blob);
     if (S.h_blob) (void)hipHostFree(S.h_blob);
@@ -188,6 +194,7 @@ JxlHipDecoder::~JxlHipDecoder() {
   for (auto p : d_dq) (void)hipFree(p);
   if (own_stream) (void)hipStreamDestroy(own_stream);
   if (stream_lf) (void)hipStreamDestroy(stream_lf);
+  if (stream_hf) (void)hipStreamDestroy(stream_hf);
 }
 
 void JxlHipDecoder::EnsureWs(size_t bytes) {
@@ -271,6 +278,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   auto& n = S.n; auto& frames = S.frames; auto& imgs = S.imgs; auto& parse_status = S.parse_status; auto& parse_msg = S.parse_msg;
   auto& status_off = S.status_off; auto& d_imgs = S.d_imgs; auto& taps = S.taps; auto& stage_names = S.stage_names;
   hipStream_t s_lf = (overlap && !debug_taps) ? stream_lf : stream;
+  hipStream_t s_hf = (overlap && !debug_taps) ? stream_hf : stream;
   n = n_;
   frames.assign(n, ParsedFrame());
   parse_status.assign(n, DecoderStatus_Ok);
@@ -370,8 +378,24 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (parse_status[i] == DecoderStatus_Ok) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
-  const int alpha_stride = lane_stride;            // same section -> lane mapping, 64-thread workgroups
-  const int per_alpha_wg = 64 / alpha_stride;
+  // Lane mapping of the alpha kernel (64-thread workgroups): one section per wavefront (split-phase decode, 64 KB of
+  // residuals in LDS) while the launch fits the chip in one round, else the largest stride whose launch still does.
+  int alpha_stride = 64;
+  if (lane_stride_override > 0) alpha_stride = lane_stride_override;
+  else {
+    size_t tab = 0;
+    int alpha_sections = 0;
+    for (int i = 0; i < n; i++)
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].alpha_index >= 0) {
+        alpha_sections += frames[i].ng;
+        tab = std::max(tab, 8 + sizeof(DevTreeNode) * frames[i].tree.size() + 8 * frames[i].mcode.alias.size() + 4 * frames[i].mcode.cfg.size() +
+                                frames[i].mcode.ctx_map.size());
+      }
+    (void)tab;
+    // measured: beyond one wavefront-per-section round, alpha decodes fastest with the HF kernel's mapping
+    alpha_stride = alpha_sections <= 512 ? 64 : std::min(lane_stride, 32);
+  }
+  const int per_alpha_wg = alpha_stride == 64 ? 1 : 4 * (64 / alpha_stride);   // 256-thread workgroups unless one section per wavefront
   int n_alpha_wg = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
@@ -526,7 +550,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
     lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64);
     lds_lf = std::max(lds_lf, 1024 + 64 * 256 * 4 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
-    lds_alpha = std::max(lds_alpha, (size_t)(64 / alpha_stride) * 1024 + (alpha_stride == 64 ? 64 * 256 * 4 : 0) +
+    lds_alpha = std::max(lds_alpha, (size_t)per_alpha_wg * 1024 + (alpha_stride == 64 ? 64 * 256 * 4 : 0) +
                                         sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
     for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
@@ -548,25 +572,31 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   Mark("lf_groups", s_lf, 0);
   LaunchLfPixelStages(d_imgs, n, max_cells, s_lf);
   Mark("lf_pixels", s_lf, 0);
-  if (s_lf != stream) {
+  // three chains, three streams: LF (batch k+2) | HF coefficients (batch k+1) | alpha + pixels (batch k)
+  if (s_lf != s_hf) {
     HIP_OK(hipEventRecord(S.lf_done, s_lf));
-    HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0));
+    HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
-  Mark("main_start", stream, 1);
+  Mark("hf_start", s_hf, 1);
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_hf <= kLdsMax ? lds_hf : 0, d_natural_small,
-                 stream);
-  Mark("hf_decode", stream, 1);
+                 s_hf);
+  Mark("hf_decode", s_hf, 1);
+  if (s_hf != stream) {
+    HIP_OK(hipEventRecord(S.hf_done, s_hf));
+    HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
+  }
+  Mark("main_start", stream, 2);
   if (any_alpha)
     LaunchAlpha(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
-  Mark("alpha", stream, 1);
+  Mark("alpha", stream, 2);
   if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
   if (any_alpha) LaunchAlphaToU8(d_imgs, n, max_pix, stream);
   LaunchReconTiles(d_imgs, n, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
   LaunchGenericReconstruct(d_imgs, n, d_basis_all, d_basis_small, d_llf_scale, stream);
-  Mark("reconstruct", stream, 1);
+  Mark("reconstruct", stream, 2);
   if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
   LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, stream);
-  Mark("filters+output", stream, 1);
+  Mark("filters+output", stream, 2);
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok)
       HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, stream));
@@ -575,7 +605,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   last_stream = stream;
   S.pending = true;
   last = cur;
-  cur ^= 1;
+  cur = (cur + 1) % kSlots;
   (void)max_padded;
   if (sync) {
     DecoderStatus st = Finish(statuses, err);
@@ -604,9 +634,10 @@ void JxlHipDecoder::CopyPlaneTap(int stage) {
 
 DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
   HIP_OK(hipSetDevice(device));
-  // older batch first (its failure, if any, becomes the sticky error), then the most recent one
-  Slot& O = slots[last ^ 1];
-  if (O.pending) {
+  // older batches first, in submission order (a failure there becomes the sticky error), then the most recent one
+  for (int k = 1; k < kSlots; k++) {
+    Slot& O = slots[(last + k) % kSlots];
+    if (!O.pending) continue;
     WaitSlot(O);
     for (int i = 0; i < O.n; i++) {
       int st = O.parse_status[i];

@@ -660,8 +660,11 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
     lds_orders = natural_orders_small;
     nnz_tab = d_nnz_ctx;
   }
-  if (threadIdx.x % lane_stride) return;
-  const int si = threadIdx.x / lane_stride;
+  // Active lanes are the FIRST 64/lane_stride lanes of every wavefront: a wave64 whose upper 32 lanes are idle issues
+  // each vector instruction in one pass instead of two.
+  const int per_wave = 64 / lane_stride;
+  if ((int)(threadIdx.x & 63) >= per_wave) return;
+  const int si = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
   if (si >= task.count) return;
   const int g = task.first + si;
   const int gx = g % im.xg, gy = g / im.xg;
@@ -782,8 +785,11 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
 }
 
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens)
+// Two mappings: lane_stride == 64 -> 64-thread workgroup = one section, split-phase decode by the whole wavefront;
+// otherwise 256-thread workgroups (one wavefront per SIMD of a CU), the first 64/lane_stride lanes of every
+// wavefront own one section each.
 template <bool kLds>
-__global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
+__global__ __launch_bounds__(256) void alpha_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
@@ -792,18 +798,21 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
   typename AS<kLds>::Tree tree;
   RowBuf<kLds> rbuf;
   JXL_LDS int32_t* resid = nullptr;
-  const int slots = 64 / lane_stride;
+  const int per_wave = 64 / lane_stride;
+  const int slots = lane_stride == 64 ? 1 : 4 * per_wave;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = wave * per_wave + (lane < per_wave ? lane : 0);
   if constexpr (kLds) {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     size_t off = 0;
-    rbuf.rb = (JXL_LDS int32_t*)lds + threadIdx.x / lane_stride; off += (size_t)slots * 256 * 4;
+    rbuf.rb = (JXL_LDS int32_t*)lds + (lane_stride == 64 ? 0 : slot); off += (size_t)slots * 256 * 4;
     rbuf.rb_stride = slots;
     rbuf.rb_width = 256;
     if (lane_stride == 64) { resid = (JXL_LDS int32_t*)(lds + off); off += 64 * 256 * 4; }
     JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
-    for (int i = threadIdx.x; i < im.tree_size; i += 64) st[i] = ((const I4*)im.tree)[i];
+    for (int i = threadIdx.x; i < im.tree_size; i += blockDim.x) st[i] = ((const I4*)im.tree)[i];
     tree = st;
-    StageCode(lds, off, im.mcode, tab, threadIdx.x, 64);
+    StageCode(lds, off, im.mcode, tab, threadIdx.x, blockDim.x);
     __syncthreads();
   } else {
     GlobalCode(im.mcode, tab);
@@ -812,7 +821,7 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
   }
   if constexpr (kLds) {
     if (lane_stride == 64) {
-      // one section per wavefront: split-phase decode by all 64 lanes when the stream allows it
+      // one section per wavefront (blockDim == 64): split-phase decode by all 64 lanes when the stream allows it
       __shared__ uint32_t s_fail;
       const int g = task.first;
       const uint64_t start = im.grp_bitpos[g];
@@ -823,8 +832,8 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
       const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
       const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
       DevTreeNode leaf;
-      bool wave = StaticLeaf<true>(tree, 0, sid, &leaf);
-      if (wave) { const uint32_t p = leaf.a & 0xFF; wave = p == 0 || p == 1 || p == 2 || p == 5; }
+      bool wavepath = StaticLeaf<true>(tree, 0, sid, &leaf);
+      if (wavepath) { const uint32_t p = leaf.a & 0xFF; wavepath = p == 0 || p == 1 || p == 2 || p == 5; }
       LaneBits b;
       uint32_t state = 0;
       if (threadIdx.x == 0) {
@@ -835,7 +844,7 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
       __syncthreads();
       if (s_fail) { if (threadIdx.x == 0) SetError(im, s_fail); return; }
       int32_t* out = im.alpha32 + (size_t)y0 * im.w + x0;
-      if (wave) {
+      if (wavepath) {
         ModularChannelWave(b, state, tab, leaf, gw, gh, out, im.w, (JXL_LDS int32_t*)smem, resid, threadIdx.x);
       } else if (threadIdx.x == 0) {
         ModularChannel<true>(b, state, tab, tree, 0, sid, gw, gh, out, im.w, rbuf);
@@ -849,8 +858,8 @@ __global__ __launch_bounds__(64) void alpha_kernel(const DevImage* imgs, const S
       return;
     }
   }
-  if (threadIdx.x % lane_stride) return;
-  const int si = threadIdx.x / lane_stride;
+  if (lane >= per_wave) return;   // the first per_wave lanes of every wavefront own one section each
+  const int si = lane_stride == 64 ? 0 : slot;
   if (si >= task.count) return;
   const int g = task.first + si;
   const uint64_t start = im.grp_bitpos[g];
@@ -903,9 +912,9 @@ void LaunchAlpha(const DevImage* imgs, const SectionTask* tasks, int nwg, int la
   if (nwg <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)alpha_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(alpha_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_kernel<true>, dim3(nwg), dim3(lane_stride == 64 ? 64 : 256), lds_bytes, s, imgs, tasks, lane_stride);
   } else {
-    hipLaunchKernelGGL(alpha_kernel<false>, dim3(nwg), dim3(64), 0, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_kernel<false>, dim3(nwg), dim3(lane_stride == 64 ? 64 : 256), 0, s, imgs, tasks, lane_stride);
   }
 }
 

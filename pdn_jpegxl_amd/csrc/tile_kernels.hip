@@ -290,15 +290,22 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
   const float* in0 = im.stage_in[kStage][0];
   const float* in1 = im.stage_in[kStage][1];
   const float* in2 = im.stage_in[kStage][2];
-  for (int e = threadIdx.x; e < LW * LH; e += 256) {
+  // staged with unconditional (clamped-index) loads in unrolled batches so that a thread's fetches overlap
+  constexpr int kLoadIters = (LW * LH + 255) / 256;
+#pragma unroll
+  for (int it = 0; it < kLoadIters; it++) {
+    const int e0 = threadIdx.x + it * 256;
+    const int e = e0 < LW * LH ? e0 : LW * LH - 1;
     const int ly = e / LW, lx = e % LW;
     const size_t g = (size_t)Mirror(y0 - HALO + ly, h) * wp + Mirror(x0 - HALO + lx, w);
-    t[0][ly][lx] = in0[g];
-    t[1][ly][lx] = in1[g];
-    t[2][ly][lx] = in2[g];
+    const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
+    t[0][ly][lx] = v0;
+    t[1][ly][lx] = v1;
+    t[2][ly][lx] = v2;
   }
   __syncthreads();
   const bool final_stage = im.final_stage == kStage;
+#pragma unroll 2
   for (int e = threadIdx.x; e < TW * TH; e += 256) {
     const int ly = e / TW, lx = e % TW;
     const int x = x0 + lx, y = y0 + ly;

@@ -96,6 +96,11 @@ struct DevImage {
   int32_t* binfo;           // scratch per LF group (kBinfoInts ints): cfl x, cfl b, block info rows, sharpness
   uint8_t* nzmap;           // scratch per group: 3 * 1024 bytes (non-zero counts per 8x8 cell)
   uint64_t* grp_bitpos;     // per group: codestream bit position after the HF tokens (~0 = failed)
+  // single-section frames (they fit one group): the sections share one bit stream
+  int32_t single, alpha_in_global;
+  uint64_t lf_start_bits;   // where the GPU starts (global alpha channel, then the LF group)
+  uint64_t hf_start_bits;   // after HfGlobal (filled in once the host has parsed it)
+  uint64_t* lf_end_bits;    // written by lf_group_kernel: bit position after the LF group
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
   int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
   float* tmp[3];            // wp*hp

@@ -512,9 +512,22 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
     if (tid == 0) ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out, stride, rbuf);
     __syncthreads();
   };
+  const int lf_sec = im.single ? 0 : 1 + g;
+  if (tid == 0) {
+    b.Init(im.cs, im.cs_size, im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8);
+    if (im.single && im.alpha_in_global) state = b.Read(32);
+    s_err = 0;
+  }
+  __syncthreads();
+  if (im.single && im.alpha_in_global) {
+    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
+    channel(0, 0, im.w, im.h, im.alpha32, im.w);
+    if (tid == 0 && state != 0x130000u) s_err = kErrBitstream;
+    __syncthreads();
+    if (s_err) { if (tid == 0) SetError(im, s_err); return; }
+  }
   if (tid == 0) {
     uint32_t err = 0;
-    b.Init(im.cs, im.cs_size, im.sec_off[1 + g] * 8);
     im.lf_extra[g] = (uint8_t)b.Read(2);
     if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
     state = b.Read(32);
@@ -555,7 +568,9 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   }
   if (tid == 0) {
     uint32_t err = 0;
-    if (state != 0x130000u || b.Consumed() > (uint64_t)im.sec_size[1 + g] * 8) err |= kErrBitstream;
+    const uint64_t start_bits = im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8;
+    if (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8) err |= kErrBitstream;
+    if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
     s_err = err;
   }
   __syncthreads();
@@ -670,8 +685,8 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   const int gx = g % im.xg, gy = g / im.xg;
   const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
   const int bw = min(kGroupBlocks, im.w8 - bx0), bh = min(kGroupBlocks, im.h8 - by0);
-  const int sec = 2 + im.nlf + g;
-  const uint64_t sec_bits = im.sec_off[sec] * 8;
+  const int sec = im.single ? 0 : 2 + im.nlf + g;
+  const uint64_t sec_bits = im.single ? im.hf_start_bits : im.sec_off[sec] * 8;
   LaneBits b;
   b.Init(im.cs, im.cs_size, sec_bits);
   const uint32_t preset = b.Read(CeilLog2D((uint32_t)im.num_presets));
@@ -779,7 +794,7 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   }
   if (!err && state != 0x130000u) err |= kErrBitstream;
   const uint64_t used = b.Consumed();
-  if (!err && used > (uint64_t)im.sec_size[sec] * 8) err |= kErrBitstream;
+  if (!err && sec_bits + used > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   im.grp_bitpos[g] = err ? ~(uint64_t)0 : sec_bits + used;
   if (err) SetError(im, err);
 }
@@ -793,7 +808,7 @@ __global__ __launch_bounds__(256) void alpha_kernel(const DevImage* imgs, const 
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
-  if (!im.has_alpha) return;
+  if (!im.has_alpha || im.alpha_in_global) return;
   CodeTab<kLds> tab;
   typename AS<kLds>::Tree tree;
   RowBuf<kLds> rbuf;

@@ -1135,14 +1135,19 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   if (f.bits != 8 || f.exp_bits != 0) Fail("only 8-bit integer samples are supported yet");
   if (f.encoding == 0 && !f.xyb_encoded) Fail("VarDCT frames without XYB are not supported yet");
   if (f.encoding == 1) Fail("Modular (lossless) frames are not decoded on the GPU path yet");
-  if (f.sec_off.size() == 1) Fail("single-group frames (<= 256x256) are not decoded on the GPU path yet");
+  f.single = f.sec_off.size() == 1;
   {
     Bits s(f.cs + f.sec_off[0], f.sec_size[0]);
     ReadLfGlobal(s, f);
+    // single-section frames: LfGlobal | LfGroup | HfGlobal | PassGroup share one bit stream; the kernels continue from here
+    f.after_lf_global_bits = f.sec_off[0] * 8 + s.pos();
   }
   if (f.tree_uses_wp || f.tree_uses_ref)
     Fail("MA trees using the weighted predictor or reference-channel properties are not supported on the GPU path yet");
   if (f.mcode.use_prefix || f.mcode.lz77) Fail("prefix-coded / LZ77 modular streams are not supported on the GPU path yet");
+  // HfGlobal of a single-section frame starts where the GPU finishes the LF group (ParseHfGlobalAt); the two-phase
+  // submission that needs is not wired into the batch pipeline yet, so say so instead of decoding garbage.
+  if (f.single) Fail("single-group frames (<= 256x256) are not decoded on the GPU path yet");
   {
     Bits s(f.cs + f.sec_off[1 + f.nlf], f.sec_size[1 + f.nlf]);
     std::vector<float> custom[kNumQuantTables];
@@ -1150,6 +1155,21 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
     if (!f.dq_default) Fail("custom quantisation tables are not supported on the GPU path yet");
   }
   if (f.acode.use_prefix || f.acode.lz77) Fail("prefix-coded / LZ77 coefficient streams are not supported on the GPU path yet");
+}
+
+uint64_t ParseHfGlobalAt(ParsedFrame& f, uint64_t bit_pos) {
+  const uint64_t sec_bits = f.sec_off[0] * 8;
+  if (bit_pos < sec_bits || bit_pos > sec_bits + (uint64_t)f.sec_size[0] * 8) Fail("LF group ends outside its section");
+  Bits s(f.cs + f.sec_off[0], f.sec_size[0]);
+  s.Skip(bit_pos - sec_bits);
+  std::vector<float> custom[kNumQuantTables];
+  ReadHfGlobal(s, f, custom);
+  if (!f.dq_default) Fail("custom quantisation tables are not supported on the GPU path yet");
+  if (f.acode.use_prefix || f.acode.lz77) Fail("prefix-coded / LZ77 coefficient streams are not supported on the GPU path yet");
+  for (int o = 0; o < kNumOrders; o++)
+    for (int c = 0; c < 3; c++)
+      if (!f.custom_order[o][c].empty()) Fail("custom coefficient orders in single-group frames are not supported on the GPU path yet");
+  return sec_bits + s.pos();
 }
 
 }  // namespace jxlhip

@@ -98,6 +98,8 @@ struct ParsedFrame {
   bool tree_uses_wp = false, tree_uses_ref = false;
   HostCode mcode;
   bool global_modular_has_channels = false;
+  bool single = false;                 // one TOC entry: all sections share one bit stream (frames that fit one group)
+  uint64_t after_lf_global_bits = 0;   // codestream bit position right after the host-parsed part of LfGlobal
   // ---- HfGlobal
   bool dq_default = true;
   uint32_t num_presets = 1;
@@ -107,6 +109,8 @@ struct ParsedFrame {
 
 // Throws ParseError.  headers_only: stop after the frame header + TOC (jxlhip_peek / pass 1 of LoadImage).
 void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame& out);
+// Single-section frames: parses HfGlobal at `bit_pos` (where the GPU finished the LF group); returns the bit position after it.
+uint64_t ParseHfGlobalAt(ParsedFrame& f, uint64_t bit_pos);
 
 // Static tables shared by every image (computed once on the host, uploaded at decoder creation).
 struct StaticTables {

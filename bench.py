@@ -8,7 +8,7 @@ value = megapixels decoded per second, whole job (all ranks).  With --gpus N eac
 (weak scaling; independent images shard with no data-path collective — DESIGN.md "Multi-GPU").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (the slowest of lf_group_kernel / hf_decode_kernel / alpha_kernel), bound = HBM;
+  roofline      dominant kernel (the slowest of lf_ans_kernel / hf_decode_kernel / alpha_ans_kernel), bound = HBM;
                 achieved = algorithmic bytes per launch (B * (jxl bytes + W*H*4)) / its HIP-event duration
   cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
 """
@@ -134,7 +134,7 @@ def main():
     if rank == 0:
         mp = W * H / 1e6
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        kernels = {"lf_groups": "lf_group_kernel", "hf_decode": "hf_decode_kernel", "alpha": "alpha_kernel"}
+        kernels = {"lf_ans": "lf_ans_kernel", "hf_decode": "hf_decode_kernel", "alpha_ans": "alpha_ans_kernel"}
         dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))   # the dominant kernel of this run
         dom_ms = stage_ms.get(dom, 0.0)
         alg_bytes = B * (len(data) + W * H * C)

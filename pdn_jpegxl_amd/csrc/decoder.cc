@@ -318,7 +318,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, nzmap, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
+    size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
   int total_lf = 0, total_groups = 0;
@@ -350,7 +350,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.ytox = ws.Take(tiles);
     l.ytob = ws.Take(tiles);
     l.binfo = ws.Take((size_t)f.nlf * kBinfoInts * 4);
-    l.nzmap = ws.Take((size_t)f.ng * 3072);
+    l.lf_desc = ws.Take((size_t)f.nlf * 8 * sizeof(ChanDesc));
+    l.lf_count = ws.Take((size_t)f.nlf * 4);
+    l.alpha_desc = ws.Take((size_t)f.ng * sizeof(ChanDesc));
+    l.blk_list = ws.Take((size_t)f.ng * 2048 * 4);
+    l.blk_count = ws.Take((size_t)f.ng * 4);
     l.bitpos = ws.Take((size_t)f.ng * 8);
     l.tile_list = ws.Take(tiles * 4);
     for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); }
@@ -367,7 +371,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     size_t lds_est = 0;
     for (int i = 0; i < n; i++)
       if (parse_status[i] == DecoderStatus_Ok)
-        lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 2 + 8448 * 2 + 64);
+        lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 2 + 8448 * 2 + 64 + 4 * (96 + 64 + 128));
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
     while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
@@ -378,27 +382,24 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (parse_status[i] == DecoderStatus_Ok) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
-  // Lane mapping of the alpha kernel (64-thread workgroups): one section per wavefront (split-phase decode, 64 KB of
-  // residuals in LDS) while the launch fits the chip in one round, else the largest stride whose launch still does.
+  // Lane mapping of the alpha phase-A kernel (one wavefront per workgroup, sections of one image per wavefront): spread the
+  // sections over as many wavefronts as the chip holds in one round, then pack.
   int alpha_stride = 64;
   if (lane_stride_override > 0) alpha_stride = lane_stride_override;
   else {
-    size_t tab = 0;
     int alpha_sections = 0;
     for (int i = 0; i < n; i++)
-      if (parse_status[i] == DecoderStatus_Ok && frames[i].alpha_index >= 0) {
-        alpha_sections += frames[i].ng;
-        tab = std::max(tab, 8 + sizeof(DevTreeNode) * frames[i].tree.size() + 8 * frames[i].mcode.alias.size() + 4 * frames[i].mcode.cfg.size() +
-                                frames[i].mcode.ctx_map.size());
-      }
-    (void)tab;
-    // measured: beyond one wavefront-per-section round, alpha decodes fastest with the HF kernel's mapping
-    alpha_stride = alpha_sections <= 512 ? 64 : std::min(lane_stride, 32);
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
+    while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
   }
-  const int per_alpha_wg = alpha_stride == 64 ? 1 : 4 * (64 / alpha_stride);   // 256-thread workgroups unless one section per wavefront
+  const int per_alpha_wg = 64 / alpha_stride;
   int n_alpha_wg = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
+  int n_lf_ans = 0;
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok) n_lf_ans += ((int)frames[i].nlf + 63) / 64;
+  const size_t off_lf_ans_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_lf_ans));
   const size_t off_alpha_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_alpha_wg));
   const size_t zero_bytes = Align(ws_zero.off, 256);
   EnsureBlob(blob.off);
@@ -418,11 +419,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
-  size_t max_cells = 1, max_pix = 1, max_padded = 8;
+  size_t max_cells = 1, max_padded = 8;
   SectionTask* lf_tasks = (SectionTask*)(h_blob + off_lf_tasks);
   SectionTask* pass_tasks = (SectionTask*)(h_blob + off_pass_tasks);
   SectionTask* alpha_tasks = (SectionTask*)(h_blob + off_alpha_tasks);
-  int nlf_t = 0, npass_t = 0, nalpha_t = 0;
+  SectionTask* lf_ans_tasks = (SectionTask*)(h_blob + off_lf_ans_tasks);
+  int nlf_t = 0, npass_t = 0, nalpha_t = 0, nlf_ans_t = 0, max_groups = 1;
   uint8_t* wz = d_ws;
   uint8_t* wr = d_ws + zero_bytes;
   for (int i = 0; i < n; i++) {
@@ -516,7 +518,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.lf_extra = wr + l.lf_extra;
     d.rawq = (uint16_t*)(wr + l.rawq); d.sharp = wr + l.sharp;
     d.ytox = (int8_t*)(wr + l.ytox); d.ytob = (int8_t*)(wr + l.ytob);
-    d.binfo = (int32_t*)(wr + l.binfo); d.nzmap = wr + l.nzmap; d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
+    d.binfo = (int32_t*)(wr + l.binfo);
+    d.lf_desc = (ChanDesc*)(wr + l.lf_desc); d.lf_count = (uint32_t*)(wr + l.lf_count); d.alpha_desc = (ChanDesc*)(wr + l.alpha_desc);
+    d.blk_list = (uint32_t*)(wr + l.blk_list); d.blk_count = (uint32_t*)(wr + l.blk_count);
+    d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
     d.tile_list = (uint32_t*)(wr + l.tile_list);
     d.alpha32 = (int32_t*)d.tmp[0];
     d.inv_sigma = (float*)(wr + l.inv_sigma);
@@ -544,14 +549,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     any_alpha |= d.has_alpha != 0;
     max_epf = std::max<int>(max_epf, f.epf_iters);
     max_cells = std::max(max_cells, (size_t)f.w8 * f.h8);
-    max_pix = std::max(max_pix, (size_t)f.xsize * f.ysize);
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-    lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64);
-    lds_lf = std::max(lds_lf, 1024 + 64 * 256 * 4 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
-    lds_alpha = std::max(lds_alpha, (size_t)per_alpha_wg * 1024 + (alpha_stride == 64 ? 64 * 256 * 4 : 0) +
-                                        sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_hf = std::max(lds_hf, (size_t)per_wg * (96 + 64 + 128) + code_lds(f.acode) + 2 + 8448 * 2 + 64);
+    lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_alpha = lds_lf;
+    max_groups = std::max<int>(max_groups, (int)f.ng);
+    for (uint32_t g = 0; g < f.nlf; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, f.nlf - g), 0};
     for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
     for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
     if (d.has_alpha)
@@ -568,10 +573,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
   const size_t kLdsMax = 150 * 1024;
-  LaunchLfGroups(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
-  Mark("lf_groups", s_lf, 0);
+  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
+  Mark("lf_ans", s_lf, 0);
+  LaunchLfFinish(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, s_lf);
+  LaunchHfBlockList(d_imgs, n, max_groups, s_lf);
   LaunchLfPixelStages(d_imgs, n, max_cells, s_lf);
-  Mark("lf_pixels", s_lf, 0);
+  Mark("lf_finish+pixels", s_lf, 0);
   // three chains, three streams: LF (batch k+2) | HF coefficients (batch k+1) | alpha + pixels (batch k)
   if (s_lf != s_hf) {
     HIP_OK(hipEventRecord(S.lf_done, s_lf));
@@ -587,10 +594,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   Mark("main_start", stream, 2);
   if (any_alpha)
-    LaunchAlpha(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
-  Mark("alpha", stream, 2);
+    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
+  Mark("alpha_ans", stream, 2);
   if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
-  if (any_alpha) LaunchAlphaToU8(d_imgs, n, max_pix, stream);
+  if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, stream);
   LaunchReconTiles(d_imgs, n, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
   LaunchGenericReconstruct(d_imgs, n, d_basis_all, d_basis_small, d_llf_scale, stream);
   Mark("reconstruct", stream, 2);
@@ -807,7 +814,8 @@ JXLFILETYPEIO_API int32_t jxlhip_stage_totals(JxlHipDecoder* dec, const char** n
     if (ms) ms[k] = (float)dec->total_ms[i];
   }
   if (batches) *batches = dec->total_batches;
-  if (reset) { dec->total_names.clear(); dec->total_ms.clear(); dec->total_batches = 0; }
+  // the names stay (the caller reads the returned pointers after this call); only the sums restart
+  if (reset) { std::fill(dec->total_ms.begin(), dec->total_ms.end(), 0.0); dec->total_batches = 0; }
   return k;
 }
 

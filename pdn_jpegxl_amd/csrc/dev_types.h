@@ -42,6 +42,18 @@ struct DevCode {
   uint32_t pad;
 };
 
+// Outcome of phase A (one lane per section) for one Modular channel; phase B (a wavefront per channel) finishes it.
+enum ChanKind : int32_t {
+  kChanFinal = 0,   // samples are final
+  kChanResid = 1,   // residuals stored in place; the row predictors (Zero / W / N / Gradient) are still to be applied
+  kChanConst = 2,   // every sample equals `value`; nothing was stored
+};
+struct ChanDesc {
+  int32_t kind;
+  int32_t value;
+  int32_t pad0, pad1;
+};
+
 struct DevImage {
   // geometry
   int32_t w, h, w8, h8, wp, hp, wt, ht;
@@ -94,7 +106,11 @@ struct DevImage {
   int8_t* ytox;             // per 64x64 tile
   int8_t* ytob;
   int32_t* binfo;           // scratch per LF group (kBinfoInts ints): cfl x, cfl b, block info rows, sharpness
-  uint8_t* nzmap;           // scratch per group: 3 * 1024 bytes (non-zero counts per 8x8 cell)
+  ChanDesc* lf_desc;        // per LF group: 8 entries (3 LF channels, 4 HF-metadata channels, spare)
+  uint32_t* lf_count;       // per LF group: number of varblocks (0 = phase A failed)
+  ChanDesc* alpha_desc;     // per group
+  uint32_t* blk_list;       // per group: 1024 x 2 words, varblocks in decode order (hf_blocklist_kernel)
+  uint32_t* blk_count;      // per group
   uint64_t* grp_bitpos;     // per group: codestream bit position after the HF tokens (~0 = failed)
   // single-section frames (they fit one group): the sections share one bit stream
   int32_t single, alpha_in_global;

@@ -39,34 +39,64 @@ __device__ __forceinline__ void SetError(const DevImage& im, uint32_t bits) { at
 #define JXL_GLB __attribute__((address_space(1)))
 // pointers read out of DevImage are generic; cast the hot ones so they compile to global_load/global_store
 template <class T> __device__ __forceinline__ JXL_GLB T* G(T* p) { return (JXL_GLB T*)p; }
-typedef int __attribute__((ext_vector_type(4))) I4;   // one MA-tree node (builtin vector: loadable from any address space)
+typedef int __attribute__((ext_vector_type(4))) I4;
+typedef unsigned __attribute__((ext_vector_type(2))) U2;   // one varblock descriptor
+typedef unsigned __attribute__((ext_vector_type(4))) U4;   // one MA-tree node (builtin vector: loadable from any address space)
 
-// ------------------------------------------------------------------ per-lane bit reader (one-word lookahead)
+// ------------------------------------------------------------------ per-lane bit reader over an LDS ring
+// vmcnt counts loads AND stores in issue order, so a reader that fetches its next word from global memory inside the
+// token loop makes every refill wait for the coefficient / sample store issued just before it (a full HBM round trip
+// per token).  Instead every lane owns a 32-word window of its stream in LDS (word j at ring[(j & 31) * slots + slot]:
+// lanes reading the same j hit distinct banks); the token loops call TopUp() every 16 tokens (a token consumes at most
+// 48 bits, so 24 words), which is the only place that waits on global memory.
+constexpr int kRingWords = 32;
+constexpr int kTopUpEvery = 16;
 struct LaneBits {
-  const JXL_GLB uint32_t* w;
-  uint32_t idx, nwords;   // idx: index of the word held in `next`
+  const JXL_GLB uint32_t* w;   // 32-byte aligned base of the lane's stream
+  JXL_LDS uint32_t* ring;
+  uint32_t rs;                 // ring stride (slots)
+  uint32_t nwords;             // words readable from w
+  uint32_t rd, filled;         // next word to consume / words [0, filled) have been staged
   uint64_t buf;
   int n;
   int skip;
-  uint32_t next;
-  __device__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off) {
+  __device__ __forceinline__ void Batch() {   // stages words [filled, filled + 8)
+    uint32_t v[8];
+    if (filled + 8 <= nwords) {
+      const U4 a = *(const JXL_GLB U4*)(w + filled), c = *(const JXL_GLB U4*)(w + filled + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = filled + i < nwords ? w[filled + i] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) ring[((filled + i) & (kRingWords - 1)) * rs] = v[i];
+    filled += 8;
+  }
+  __device__ __forceinline__ void TopUp() {
+    while (filled + 8 <= rd + kRingWords) Batch();
+  }
+  __device__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off, JXL_LDS uint32_t* ring_slot, uint32_t ring_stride) {
     const uintptr_t addr = (uintptr_t)cs + (bit_off >> 3);
-    const uintptr_t al = addr & ~(uintptr_t)3;
+    const uintptr_t al = addr & ~(uintptr_t)31;
     w = (const JXL_GLB uint32_t*)al;
-    nwords = (uint32_t)(((uintptr_t)(cs + cs_size) + 3 - al) >> 2);
-    idx = 0; buf = 0; n = 0;
+    ring = ring_slot; rs = ring_stride;
+    const uintptr_t end = ((uintptr_t)cs + cs_size + 3) & ~(uintptr_t)3;
+    nwords = end > al ? (uint32_t)((end - al) >> 2) : 0u;
+    rd = 0; filled = 0; buf = 0; n = 0;
     skip = (int)(addr - al) * 8 + (int)(bit_off & 7);
-    next = nwords ? w[0] : 0u;
+    TopUp();
+    rd = (uint32_t)skip >> 5;   // whole words before the start are skipped, the rest bit by bit
     Refill();
-    buf >>= skip;
-    n -= skip;
+    const int s2 = skip & 31;
+    buf >>= s2;
+    n -= s2;
   }
   __device__ __forceinline__ void Refill() {
     if (n <= 32) {
-      buf |= (uint64_t)next << n;
+      buf |= (uint64_t)ring[(rd & (kRingWords - 1)) * rs] << n;
       n += 32;
-      idx++;
-      next = idx < nwords ? w[idx] : 0u;
+      rd++;
     }
   }
   __device__ __forceinline__ uint32_t Read(int k) {   // k <= 32
@@ -77,7 +107,7 @@ struct LaneBits {
     return v;
   }
   // bits consumed since Init (relative to the bit offset given to Init)
-  __device__ uint64_t Consumed() const { return (uint64_t)idx * 32 - n - skip; }
+  __device__ uint64_t Consumed() const { return (uint64_t)rd * 32 - n - skip; }
 };
 
 template <bool kLds> struct AS;
@@ -200,6 +230,7 @@ __device__ __forceinline__ void LeafRow(LaneBits& b, uint32_t& state, const Code
   const JXL_GLB int32_t* prow = row - stride;
   int32_t W = y ? (use_rb ? rb[0] : prow[0]) : 0, N = W, NW = W;
   for (int x = 0; x < w; x++) {
+    if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
     int32_t NE = N;
     if (kPred != 0 && kPred != 1) {
       if (x + 1 < w && y) NE = use_rb ? rb[(x + 1) * rs] : prow[x + 1];
@@ -276,6 +307,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
       N = W; NW = W; WW = W;
       prev9 = 0;
     }
+    if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
     const int32_t NE = (x + 1 < w && y) ? (use_rb ? rb[(x + 1) * rs] : prow[x + 1]) : N;
     DevTreeNode nd = leaf;
     if (!row_leaf) {
@@ -351,138 +383,271 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
   }
 }
 
-// Resolves the MA tree of (chan, stream_id) on static properties only.  Returns true when that already ends in a
-// leaf, i.e. neither the context nor the predictor of any sample depends on decoded samples or on the position.
-template <bool kLds>
-__device__ bool StaticLeaf(typename AS<kLds>::Tree tree, int chan, int stream_id, DevTreeNode* leaf) {
-  int root = 0;
+// ------------------------------------------------------------------ row-static channels (two-phase decode)
+// A channel is "row-static" when, for every row, the MA-tree walk ends in a leaf using only the static properties
+// (channel, stream, row).  Its tokens then need no decoded neighbour: phase A (one lane per section, *_ans_kernel)
+// turns the ANS stream into residuals stored in the output plane; phase B (*_finish_kernel, a whole wavefront per
+// channel) applies the predictors.  Everything else takes the generic per-lane ModularChannel path in phase A.
+constexpr int kCarryInts = 1024;   // widest channel whose last row can be carried between 64-row batches in LDS
+
+template <class TreeP>
+__device__ __forceinline__ DevTreeNode RowNode(TreeP tree, int chan, int sid, int y, bool* used_y) {
   DevTreeNode nd = NodeOf(tree[0]);
-  while (nd.property == 0 || nd.property == 1) {
-    const int v = nd.property == 0 ? chan : stream_id;
-    root = v > nd.splitval ? nd.a : nd.b;
-    nd = NodeOf(tree[root]);
+  while (nd.property >= 0 && nd.property <= 2) {
+    if (nd.property == 2) *used_y = true;
+    const int v = nd.property == 0 ? chan : (nd.property == 1 ? sid : y);
+    nd = NodeOf(tree[v > nd.splitval ? nd.a : nd.b]);
   }
-  *leaf = nd;
-  return nd.property < 0;
+  return nd;
 }
 
-// Split-phase decode of one channel by a whole wavefront (64 lanes, LDS variant only).  Precondition: StaticLeaf()
-// holds with predictor Zero / W / N / Gradient and w <= 256.  Per batch of up to 64 rows:
-//   phase A (lane 0): the serial part — ANS + hybrid-uint tokens -> residuals in LDS (`resid`, 64 x 256);
-//   phase B (all lanes): lane r reconstructs row r, skewed by one sample per row, so that N comes from lane r-1's
-//            previous step (one DPP shuffle), NW is the lane's own previous N and W its own previous value.
-// `b` and `state` are meaningful in lane 0 only.  rb: LDS row (>= w ints) carrying the last row between batches.
-__device__ void ModularChannelWave(LaneBits& b, uint32_t& state, const CodeTab<true>& tab, const DevTreeNode& leaf, int w, int h,
-                                   int32_t* out_generic, int stride, JXL_LDS int32_t* rb, JXL_LDS int32_t* resid, int lane) {
+__device__ __forceinline__ bool SkewPred(uint32_t p) { return p == 0 || p == 1 || p == 2 || p == 5; }
+
+// 0: generic path; 1: row-static (needs_n: some row predicts from the row above); 2: constant channel (*cval)
+template <bool kLds>
+__device__ int ClassifyChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid, int w, int h, bool* needs_n,
+                               int32_t* cval) {
+  bool all_const = true, first = true, nn = false;
+  int32_t cv = 0;
+  for (int y = 0; y < h; y++) {
+    bool used_y = false;
+    const DevTreeNode nd = RowNode(tree, chan, sid, y, &used_y);
+    if (nd.property >= 0) return 0;
+    const uint32_t p = nd.a & 0xFF;
+    if (!SkewPred(p)) return 0;
+    if (p == 2 || p == 5) nn = true;
+    const uint32_t c = tab.cfg[tab.cmap[nd.a >> 8]];
+    const uint32_t sym = (c >> 16) & 0xFF;
+    if (p == 0 && (c & 0x1000) && sym < (1u << (c & 0xF))) {
+      const int32_t v = (int32_t)((uint32_t)UnpackSigned(sym) * nd.b + (uint32_t)nd.splitval);
+      if (first) { cv = v; first = false; }
+      else if (v != cv) all_const = false;
+    } else {
+      all_const = false;
+    }
+    if (!used_y) break;   // every row resolves to this leaf
+  }
+  if (nn && h > 64 && w > kCarryInts) return 0;
+  *needs_n = nn;
+  *cval = cv;
+  return all_const ? 2 : 1;
+}
+
+// Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
+template <bool kLds>
+__device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
+                                  int w, int h, int32_t* out_generic, int stride, ChanDesc* desc) {
+  ChanDesc d;
+  d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
+  if (w <= 0 || h <= 0) { *desc = d; return; }
+  bool needs_n = false;
+  int32_t cval = 0;
+  const int cls = ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
+  if (cls == 2) { d.kind = kChanConst; d.value = cval; *desc = d; return; }
+  if (cls == 0) {
+    RowBuf<kLds> rbuf;
+    rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
+    ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf);
+    *desc = d;
+    return;
+  }
   JXL_GLB int32_t* const out = G(out_generic);
-  const uint32_t pred = leaf.a & 0xFF;
-  const uint32_t cl = tab.cmap[leaf.a >> 8];
-  const uint32_t cfg = tab.cfg[cl];
-  const AS<true>::U64 abase = tab.alias + (cl << tab.log_alpha);
-  const bool constant_token = (cfg & 0x1000) && ((cfg >> 16) & 0xFF) < (1u << (cfg & 0xF));
-  const uint32_t const_res = (uint32_t)UnpackSigned((cfg >> 16) & 0xFF) * leaf.b + (uint32_t)leaf.splitval;
+  JXL_GLB int32_t* row = out;
+  typename AS<kLds>::U64 abase = tab.alias;
+  uint32_t cfg = 0, mul = 1, off = 0, cres = 0, pred = 0, W = 0, first_prev = 0, first_cur = 0;
+  bool ctok = false;
+  int x = 0, y = 0;
+  while (y < h) {
+    if (x == 0) {
+      bool used_y = false;
+      const DevTreeNode nd = RowNode(tree, chan, sid, y, &used_y);
+      const uint32_t cl = tab.cmap[nd.a >> 8];
+      cfg = tab.cfg[cl];
+      abase = tab.alias + (cl << tab.log_alpha);
+      mul = nd.b; off = (uint32_t)nd.splitval; pred = nd.a & 0xFF;
+      const uint32_t sym = (cfg >> 16) & 0xFF;
+      ctok = (cfg & 0x1000) && sym < (1u << (cfg & 0xF));
+      cres = (uint32_t)UnpackSigned(sym) * mul + off;
+      row = out + (size_t)y * stride;
+    }
+    if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
+    uint32_t val;
+    if (ctok) val = cres;
+    else {
+      const uint32_t sym = AnsSym<kLds>(b, state, abase, tab.log_alpha);
+      val = (uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * mul + off;
+    }
+    // Zero / West predictors need no row above: applied inline unless the channel goes through phase B anyway
+    if (!needs_n && pred == 1) val += x == 0 ? (y ? first_prev : 0u) : W;
+    row[x] = (int32_t)val;
+    W = val;
+    if (x == 0) first_cur = val;
+    if (++x == w) { x = 0; y++; first_prev = first_cur; }
+  }
+  d.kind = needs_n ? kChanResid : kChanFinal;
+  *desc = d;
+}
+
+// Phase B: a wavefront applies the predictors of a row-static channel in place.  Lane r owns row y0 + r of a 64-row
+// batch, skewed by one sample per row: N comes from lane r-1's previous step (one DPP shuffle), NW is the lane's own
+// previous N, W its own previous value.  carry: LDS row (w ints, only used when h > 64) holding the batch's last row.
+template <bool kU8Out>
+__device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
+                            uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, int lane) {
+  JXL_GLB int32_t* const plane = G(plane_generic);
+  JXL_GLB uint8_t* const out8 = G(out8_generic);
   for (int y0 = 0; y0 < h; y0 += 64) {
     const int nrows = min(64, h - y0);
-    if (lane == 0 && !constant_token) {
-      const int n = nrows * w;
-      int x = 0, r = 0;
-      for (int i = 0; i < n; i++) {
-        const uint32_t sym = AnsSym<true>(b, state, abase, tab.log_alpha);
-        resid[r * 256 + x] = (int32_t)((uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * leaf.b + (uint32_t)leaf.splitval);
-        if (++x == w) { x = 0; r++; }
-      }
-    }
-    __syncthreads();
-    {
-      const int y = y0 + lane;
-      const bool row_active = lane < nrows;
-      int32_t W = 0, N = 0, NW = 0, val = 0;
-      const int steps = w + nrows - 1;
-      for (int t = 0; t < steps; t++) {
-        const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
-        const int x = t - lane;
-        if (row_active && x >= 0 && x < w) {
-          int32_t n_in;
-          if (lane == 0) n_in = y ? rb[x] : 0;
-          else n_in = from_up;
-          if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
-          else if (y) { NW = N; N = n_in; }
-          else { NW = W; N = W; }
-          uint32_t guess;
-          if (pred == 0) guess = 0;
-          else if (pred == 1) guess = (uint32_t)W;
-          else if (pred == 2) guess = (uint32_t)N;
-          else {
-            const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
-            guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
-          }
-          const uint32_t res = constant_token ? const_res : (uint32_t)resid[lane * 256 + x];
-          val = (int32_t)(res + guess);
-          out[(size_t)y * stride + x] = val;
-          if (lane == nrows - 1) rb[x] = val;
-          W = val;
+    const int y = y0 + lane;
+    const bool row_active = lane < nrows;
+    uint32_t pred = 0;
+    if (row_active) { bool u = false; pred = RowNode(tree, chan, sid, y, &u).a & 0xFF; }
+    JXL_GLB int32_t* const prow = plane + (size_t)(row_active ? y : y0) * stride;
+    const bool more = y0 + 64 < h;
+    int32_t W = 0, N = 0, NW = 0, val = 0;
+    int32_t r_next = (row_active && lane == 0 && kind == kChanResid) ? prow[0] : cvalue;
+    const int steps = w + nrows - 1;
+    for (int t = 0; t < steps; t++) {
+      const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
+      const int x = t - lane;
+      const int32_t r = r_next;
+      if (row_active && kind == kChanResid && x + 1 >= 0 && x + 1 < w) r_next = prow[x + 1];   // in flight during this step
+      if (row_active && x >= 0 && x < w) {
+        const int32_t n_in = lane == 0 ? (y ? carry[x] : 0) : from_up;
+        if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
+        else if (y) { NW = N; N = n_in; }
+        else { NW = W; N = W; }
+        uint32_t guess;
+        if (pred == 0) guess = 0;
+        else if (pred == 1) guess = (uint32_t)W;
+        else if (pred == 2) guess = (uint32_t)N;
+        else {
+          const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
+          guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
         }
+        val = (int32_t)((uint32_t)r + guess);
+        if (kU8Out) out8[(size_t)y * out_stride + x] = (uint8_t)(val < 0 ? 0 : (val > 255 ? 255 : val));
+        else prow[x] = val;
+        if (more && lane == nrows - 1) carry[x] = val;
+        W = val;
       }
     }
-    __syncthreads();
   }
 }
 
-// If channel `chan` of stream `stream_id` resolves (on static properties only) to a leaf with the Zero
-// predictor whose cluster is degenerate (one symbol, no extra bits), every sample equals a constant that
-// can be written without touching the stream.  Returns true and the constant.
-template <bool kLds>
-__device__ bool ConstantChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int stream_id, int32_t* value) {
-  int root = 0;
-  DevTreeNode nd = NodeOf(tree[0]);
-  while (nd.property == 0 || nd.property == 1) {
-    const int v = nd.property == 0 ? chan : stream_id;
-    root = v > nd.splitval ? nd.a : nd.b;
-    nd = NodeOf(tree[root]);
+// Applies a channel descriptor to an int32 plane (phase B for planes that stay int32).
+__device__ void FinishChannelI32(const ChanDesc d, const I4* tree, int chan, int sid, int32_t* plane, int stride, int w, int h,
+                                 JXL_LDS int32_t* carry, int lane) {
+  if (w <= 0 || h <= 0) return;
+  if (d.kind == kChanConst) {
+    for (int i = lane; i < w * h; i += 64) plane[(size_t)(i / w) * stride + (i % w)] = d.value;
+  } else if (d.kind == kChanResid) {
+    PredictWave<false>(tree, chan, sid, plane, stride, w, h, d.kind, d.value, nullptr, 0, carry, lane);
   }
-  if (nd.property >= 0 || (nd.a & 0xFF) != 0) return false;
-  const uint32_t c = tab.cfg[tab.cmap[nd.a >> 8]];
-  if (!(c & 0x1000)) return false;
-  const uint32_t sym = (c >> 16) & 0xFF;
-  if (sym >= (1u << (c & 0xF))) return false;
-  *value = (int32_t)((int64_t)UnpackSigned(sym) * (int64_t)nd.b + nd.splitval);
-  return true;
+}
+
+template <bool kLds>
+struct ModTables {
+  CodeTab<kLds> tab;
+  typename AS<kLds>::Tree tree;
+};
+
+// Stages the MA tree + modular code of `im` (LDS variant) or points at them in global memory.
+template <bool kLds>
+__device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem, size_t off, ModTables<kLds>& t, int tid, int nt) {
+  if constexpr (kLds) {
+    JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
+    off = (off + 15) & ~(size_t)15;
+    JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
+    for (int i = tid; i < im.tree_size; i += nt) st[i] = ((const I4*)im.tree)[i];
+    t.tree = st;
+    StageCode(lds, off, im.mcode, t.tab, tid, nt);
+    __syncthreads();
+  } else {
+    GlobalCode(im.mcode, t.tab);
+    t.tree = (const I4*)im.tree;
+  }
 }
 
 }  // namespace
 
-// ------------------------------------------------------------------ LF groups: one workgroup (one wavefront) per LF group
+// ------------------------------------------------------------------ LF groups, phase A: one lane per LF group
+// (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
+// metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds>
-__global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, const SectionTask* tasks) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks) {
   extern __shared__ __align__(16) uint8_t smem[];
-  __shared__ uint32_t s_err;
+  const SectionTask task = tasks[blockIdx.x];
+  const DevImage& im = imgs[task.image];
+  ModTables<kLds> mt;
+  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  const int lane = threadIdx.x;
+  if (lane >= task.count) return;
+  const int g = task.first + lane;
+  const int gx = g % im.xlf, gy = g / im.xlf;
+  const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
+  const int bw = min(kLfGroupBlocks, im.w8 - bx0), bh = min(kLfGroupBlocks, im.h8 - by0);
+  const int tw = (bw + 7) / 8, th = (bh + 7) / 8;
+  int32_t* scratch = im.binfo + (size_t)g * kBinfoInts;
+  ChanDesc* desc = im.lf_desc + (size_t)g * 8;
+  const int sid_meta = 1 + 2 * im.nlf + g;
+  const int lf_sec = im.single ? 0 : 1 + g;
+  const uint64_t start_bits = im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8;
+  LaneBits b;
+  b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
+  uint32_t state = 0, err = 0, count = 1;
+  if (im.single && im.alpha_in_global) {
+    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
+    state = b.Read(32);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc);
+    if (state != 0x130000u) err |= kErrBitstream;
+  }
+  if (!err) {
+    im.lf_extra[g] = (uint8_t)b.Read(2);
+    if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
+  }
+  // seven channels, one loop (a single inlined copy of the channel decoder): 0-2 LF coefficients, 3-6 HF metadata
+#pragma unroll 1
+  for (int i = 0; i < 7 && !err; i++) {
+    if (i == 0) state = b.Read(32);
+    if (i == 3) {
+      if (state != 0x130000u) { err |= kErrBitstream; break; }
+      count = b.Read(CeilLog2D((uint32_t)(bw * bh))) + 1;
+      if (count > (uint32_t)(bw * bh)) { err |= kErrBlockLayout; break; }
+      if (b.Read(4) != 3) { err |= kErrUnsupportedHeader; break; }
+      state = b.Read(32);
+    }
+    int chan, sid, w, h, stride;
+    int32_t* out;
+    if (i < 3) {
+      const int c = i == 0 ? 1 : (i == 1 ? 0 : 2);   // modular channel order Y, X, B
+      chan = i; sid = 1 + g; w = bw; h = bh; stride = im.w8;
+      out = im.lfq[c] + (size_t)by0 * im.w8 + bx0;
+    } else {
+      chan = i - 3; sid = sid_meta;
+      if (i < 5) { w = tw; h = th; stride = tw; out = scratch + (i - 3) * 1024; }
+      else if (i == 5) { w = (int)count; h = 2; stride = (int)count; out = scratch + 2048; }
+      else { w = bw; h = bh; stride = bw; out = scratch + 2048 + 2 * 65536; }
+    }
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, desc + i);
+  }
+  if (!err && (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
+  if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
+  im.lf_count[g] = err ? 0u : count;
+  if (err) SetError(im, err);
+}
+
+// ------------------------------------------------------------------ LF groups, phase B: one workgroup (4 wavefronts) per LF group
+// Predictors of the row-static channels, then the chroma-from-luma / sharpness maps and the varblock placement.
+__global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, const SectionTask* tasks) {
+  __shared__ int32_t s_carry[4][256];
   __shared__ uint32_t s_count;
   __shared__ uint32_t s_cov[256 * 8];   // coverage bitmap of the LF group's 256 x 256 cells
   const DevImage& im = imgs[tasks[blockIdx.x].image];
   const int g = tasks[blockIdx.x].first;
-  const int tid = threadIdx.x;
-  CodeTab<kLds> tab;
-  typename AS<kLds>::Tree tree;
-  RowBuf<kLds> rbuf;
-  JXL_LDS int32_t* resid = nullptr;
-  if constexpr (kLds) {
-    JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
-    size_t off = 0;
-    rbuf.rb = (JXL_LDS int32_t*)lds; off += 256 * 4;
-    resid = (JXL_LDS int32_t*)(lds + off); off += 64 * 256 * 4;
-    JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
-    for (int i = tid; i < im.tree_size; i += 64) st[i] = ((const I4*)im.tree)[i];
-    tree = st;
-    StageCode(lds, off, im.mcode, tab, tid, 64);
-    rbuf.rb_stride = 1;
-    rbuf.rb_width = 256;
-  } else {
-    GlobalCode(im.mcode, tab);
-    tree = (const I4*)im.tree;
-    rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
-  }
-  if (tid == 0) s_err = 0;
-  __syncthreads();
+  const uint32_t count = im.lf_count[g];
+  if (!count) return;   // phase A failed (already reported)
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int gx = g % im.xlf, gy = g / im.xlf;
   const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
   const int bw = min(kLfGroupBlocks, im.w8 - bx0), bh = min(kLfGroupBlocks, im.h8 - by0);
@@ -492,100 +657,32 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   int32_t* s_b = scratch + 1024;
   int32_t* s_info = scratch + 2048;
   int32_t* s_sharp = scratch + 2048 + 2 * 65536;
+  const ChanDesc* desc = im.lf_desc + (size_t)g * 8;
+  const I4* tree = (const I4*)im.tree;
   const int sid_meta = 1 + 2 * im.nlf + g;
-  LaneBits b;
-  uint32_t state = 0;
-  // Decodes one channel: wavefront split-phase when the stream allows it, else serially on lane 0.
-  auto channel = [&](int chan, int sid, int w, int h, int32_t* out, int stride) {
-    DevTreeNode leaf;
-    bool wave = false;
-    if constexpr (kLds) {
-      if (w <= 256 && StaticLeaf<kLds>(tree, chan, sid, &leaf)) {
-        const uint32_t p = leaf.a & 0xFF;
-        wave = p == 0 || p == 1 || p == 2 || p == 5;
-      }
-      if (wave) {
-        ModularChannelWave(b, state, tab, leaf, w, h, out, stride, rbuf.rb, resid, tid);
-        return;
-      }
-    }
-    if (tid == 0) ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out, stride, rbuf);
-    __syncthreads();
-  };
-  const int lf_sec = im.single ? 0 : 1 + g;
-  if (tid == 0) {
-    b.Init(im.cs, im.cs_size, im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8);
-    if (im.single && im.alpha_in_global) state = b.Read(32);
-    s_err = 0;
-  }
-  __syncthreads();
-  if (im.single && im.alpha_in_global) {
-    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
-    channel(0, 0, im.w, im.h, im.alpha32, im.w);
-    if (tid == 0 && state != 0x130000u) s_err = kErrBitstream;
-    __syncthreads();
-    if (s_err) { if (tid == 0) SetError(im, s_err); return; }
-  }
-  if (tid == 0) {
-    uint32_t err = 0;
-    im.lf_extra[g] = (uint8_t)b.Read(2);
-    if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
-    state = b.Read(32);
-    s_err = err;
-  }
-  __syncthreads();
-  if (s_err) { if (tid == 0) SetError(im, s_err); return; }
-  {
+  JXL_LDS int32_t* carry = (JXL_LDS int32_t*)s_carry[wave];
+  if (wave < 3) {
     const int chan_of[3] = {1, 0, 2};
-    for (int mc = 0; mc < 3; mc++) channel(mc, 1 + g, bw, bh, im.lfq[chan_of[mc]] + (size_t)by0 * im.w8 + bx0, im.w8);
+    FinishChannelI32(desc[wave], tree, wave, 1 + g, im.lfq[chan_of[wave]] + (size_t)by0 * im.w8 + bx0, im.w8, bw, bh, carry, lane);
+  } else {
+    FinishChannelI32(desc[3], tree, 0, sid_meta, s_x, tw, tw, th, carry, lane);
+    FinishChannelI32(desc[4], tree, 1, sid_meta, s_b, tw, tw, th, carry, lane);
+    FinishChannelI32(desc[5], tree, 2, sid_meta, s_info, (int)count, (int)count, 2, carry, lane);
+    FinishChannelI32(desc[6], tree, 3, sid_meta, s_sharp, bw, bw, bh, carry, lane);
   }
-  if (tid == 0) {
-    uint32_t err = 0, count = 1;
-    if (state != 0x130000u) err |= kErrBitstream;
-    if (!err) {
-      count = b.Read(CeilLog2D((uint32_t)(bw * bh))) + 1;
-      if (count > (uint32_t)(bw * bh)) err |= kErrBlockLayout;
-      else if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
-      state = b.Read(32);
-    }
-    s_err = err;
-    s_count = count;
-  }
+  __threadfence_block();
   __syncthreads();
-  if (s_err) { if (tid == 0) SetError(im, s_err); return; }
-  const uint32_t count = s_count;
-  {
-    // channels whose value is a stream-independent constant are filled by the whole wavefront
-    int32_t cval;
-    if (ConstantChannel<kLds>(tab, tree, 0, sid_meta, &cval)) { for (int i = tid; i < tw * th; i += 64) s_x[i] = cval; }
-    else channel(0, sid_meta, tw, th, s_x, tw);
-    if (ConstantChannel<kLds>(tab, tree, 1, sid_meta, &cval)) { for (int i = tid; i < tw * th; i += 64) s_b[i] = cval; }
-    else channel(1, sid_meta, tw, th, s_b, tw);
-    if (ConstantChannel<kLds>(tab, tree, 2, sid_meta, &cval)) { for (uint32_t i = tid; i < 2 * count; i += 64) s_info[i] = cval; }
-    else channel(2, sid_meta, (int)count, 2, s_info, (int)count);
-    if (ConstantChannel<kLds>(tab, tree, 3, sid_meta, &cval)) { for (int i = tid; i < bw * bh; i += 64) s_sharp[i] = cval; }
-    else channel(3, sid_meta, bw, bh, s_sharp, bw);
-  }
-  if (tid == 0) {
-    uint32_t err = 0;
-    const uint64_t start_bits = im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8;
-    if (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8) err |= kErrBitstream;
-    if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
-    s_err = err;
-  }
-  __syncthreads();
-  if (s_err) { if (tid == 0) SetError(im, s_err); return; }
   // chroma-from-luma maps and sharpness: parallel copies with range checks
   uint32_t err = 0;
   const int tx0 = bx0 / 8, ty0 = by0 / 8;
-  for (int i = tid; i < tw * th; i += 64) {
+  for (int i = tid; i < tw * th; i += 256) {
     const int x = i % tw, y = i / tw;
     const int vx = s_x[i], vb = s_b[i];
     if (vx < -128 || vx > 127 || vb < -128 || vb > 127) err |= kErrRange;
     im.ytox[(size_t)(ty0 + y) * im.wt + tx0 + x] = (int8_t)vx;
     im.ytob[(size_t)(ty0 + y) * im.wt + tx0 + x] = (int8_t)vb;
   }
-  for (int i = tid; i < bw * bh; i += 64) {
+  for (int i = tid; i < bw * bh; i += 256) {
     const int x = i % bw, y = i / bw;
     int sh = s_sharp[i];
     if (sh < 0 || sh > 7) { err |= kErrRange; sh = 0; }
@@ -597,7 +694,7 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
   // per-cell fan-out (cellinfo / raw quant of every covered cell) is then done by all lanes.
   int32_t* s_pos = s_sharp;
   if (tid == 0) s_count = 0;
-  for (int i = tid; i < 256 * 8; i += 64) s_cov[i] = 0;
+  for (int i = tid; i < 256 * 8; i += 256) s_cov[i] = 0;
   __syncthreads();
   if (tid == 0) {
     uint32_t num = 0;
@@ -630,9 +727,10 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
     if (num != count) err |= kErrBlockLayout;
     s_count = num;
   }
+  __threadfence_block();
   __syncthreads();
   const uint32_t placed = s_count;
-  for (uint32_t i = tid; i < placed; i += 64) {
+  for (uint32_t i = tid; i < placed; i += 256) {
     const int x = s_pos[i] & 0xFF, y = s_pos[i] >> 8;
     const int s = s_info[i], q = 1 + s_info[count + i];
     const int lcx = d_log2cx[s], lcy = d_log2cy[s], cx = 1 << lcx, cy = 1 << lcy;
@@ -648,107 +746,178 @@ __global__ __launch_bounds__(64) void lf_group_kernel(const DevImage* imgs, cons
 }
 
 // ------------------------------------------------------------------ HF coefficients
-// One lane per group section (lane_stride spreads sections over wavefronts).  The loop decodes exactly one
-// token per iteration: the number-of-nonzeros token of a (block, channel) or one coefficient token.
+// Pre-pass (fully parallel, one wavefront per group): the varblocks of the group in decode order, each with the block
+// context of its three channels, so that the serial token loop below never waits on cellinfo / raw-quant / context-map
+// loads: it streams 8-byte descriptors, fetched one block ahead.
+//   word0 = bx | by << 5 | strategy << 10 | log2cx << 15 | log2cy << 18 | order bucket << 21
+//   word1 = block context of Y | X << 8 | B << 16
+__global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  const int g = blockIdx.x;
+  if (g >= im.ng) return;
+  const int lane = threadIdx.x;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
+  const int bw = min(kGroupBlocks, im.w8 - bx0), bh = min(kGroupBlocks, im.h8 - by0);
+  U2* list = (U2*)(im.blk_list + (size_t)g * 2048);
+  const int n_qf = im.n_qf;
+  uint32_t total = 0;
+  for (int it = 0; it < 16; it++) {
+    const int idx = it * 64 + lane;
+    const int bx = idx & 31, by = idx >> 5;
+    bool first = false;
+    uint32_t info = 0;
+    if (bx < bw && by < bh) {
+      info = im.cellinfo[(size_t)(by0 + by) * im.w8 + bx0 + bx];
+      first = (info & 0x8003FF00u) == 0x80000000u;
+    }
+    const uint64_t m = __ballot(first);
+    if (first) {
+      const uint32_t pos = total + (uint32_t)__popcll(m & (((uint64_t)1 << lane) - 1));
+      const uint32_t s = info & 0xFF, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+      const uint32_t ord = d_order_bucket[s];
+      const uint32_t rq = im.rawq[(size_t)(by0 + by) * im.w8 + bx0 + bx];
+      uint32_t qf_idx = 0;
+      for (int i = 0; i < n_qf; i++) qf_idx += rq > im.qf_thr[i];
+      uint32_t ctxs = 0;
+      for (int ci = 0; ci < 3; ci++) {
+        const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+        const uint32_t cprime = c < 2 ? (c ^ 1) : 2;
+        ctxs |= (uint32_t)im.block_ctx_map[(cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx] << (8 * ci);
+      }
+      U2 d;
+      d.x = (uint32_t)bx | (uint32_t)by << 5 | s << 10 | lcx << 15 | lcy << 18 | ord << 21;
+      d.y = ctxs;
+      list[pos] = d;
+    }
+    total += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) im.blk_count[g] = total;
+}
+
+// One lane per group section (lane_stride spreads sections over wavefronts).  The loop decodes exactly one token per
+// iteration: the number-of-nonzeros token of a (block, channel) or one coefficient token.  Per-lane state that the
+// context model needs (non-zero counts of the row above / the cell to the left) is a 32-entry column buffer per
+// channel in LDS: col[x] = value of the last decoded block covering column x, which is both "above" and "left".
 template <bool kLds>
 __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride,
                                                         const uint16_t* natural_orders_small) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
+  const int per_wave = 64 / lane_stride;
+  const int nslots = 4 * per_wave;
   CodeTab<kLds> tab;
   typename AS<kLds>::U16 lds_orders;
   typename AS<kLds>::U8 nnz_tab;
-  if constexpr (kLds) {
+  typename AS<kLds>::U16 order_off;
+  JXL_LDS uint8_t* nzcol;
+  JXL_LDS uint32_t* ring_base;
+  JXL_LDS U2* descq;   // per lane: queue of the next 8 varblock descriptors, entry j at descq[(j & 7) * nslots + slot]
+  {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
-    size_t off = StageCode(lds, 0, im.acode, tab, threadIdx.x, blockDim.x);
-    off = (off + 1) & ~(size_t)1;
-    JXL_LDS uint16_t* so = (JXL_LDS uint16_t*)(lds + off); off += 8448 * 2;
-    for (int i = threadIdx.x; i < 8448; i += blockDim.x) so[i] = natural_orders_small[i];
-    JXL_LDS uint8_t* sn = lds + off; off += 64;
-    if (threadIdx.x < 64) sn[threadIdx.x] = d_nnz_ctx[threadIdx.x];
-    lds_orders = so;
-    nnz_tab = sn;
-    __syncthreads();
-  } else {
-    GlobalCode(im.acode, tab);
-    lds_orders = natural_orders_small;
-    nnz_tab = d_nnz_ctx;
+    size_t off = 0;
+    ring_base = (JXL_LDS uint32_t*)lds; off += (size_t)nslots * kRingWords * 4;
+    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * 8 * 8;
+    nzcol = lds + off; off += (size_t)nslots * 96;
+    if constexpr (kLds) {
+      off = StageCode(lds, off, im.acode, tab, threadIdx.x, blockDim.x);
+      off = (off + 1) & ~(size_t)1;
+      JXL_LDS uint16_t* so = (JXL_LDS uint16_t*)(lds + off); off += 8448 * 2;
+      for (int i = threadIdx.x; i < 8448; i += blockDim.x) so[i] = natural_orders_small[i];
+      JXL_LDS uint8_t* sn = lds + off; off += 64;
+      if (threadIdx.x < 64) sn[threadIdx.x] = d_nnz_ctx[threadIdx.x];
+      JXL_LDS uint16_t* oo = (JXL_LDS uint16_t*)(lds + off); off += 20;
+      if (threadIdx.x < 10) oo[threadIdx.x] = d_order_lds_off[threadIdx.x];
+      lds_orders = so;
+      nnz_tab = sn;
+      order_off = oo;
+      __syncthreads();
+    } else {
+      GlobalCode(im.acode, tab);
+      lds_orders = natural_orders_small;
+      nnz_tab = d_nnz_ctx;
+      order_off = d_order_lds_off;
+    }
   }
   // Active lanes are the FIRST 64/lane_stride lanes of every wavefront: a wave64 whose upper 32 lanes are idle issues
   // each vector instruction in one pass instead of two.
-  const int per_wave = 64 / lane_stride;
   if ((int)(threadIdx.x & 63) >= per_wave) return;
   const int si = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
   if (si >= task.count) return;
+  JXL_LDS uint8_t* const col = nzcol + si;   // col[(c * 32 + x) * nslots]
   const int g = task.first + si;
-  const int gx = g % im.xg, gy = g / im.xg;
-  const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
-  const int bw = min(kGroupBlocks, im.w8 - bx0), bh = min(kGroupBlocks, im.h8 - by0);
   const int sec = im.single ? 0 : 2 + im.nlf + g;
   const uint64_t sec_bits = im.single ? im.hf_start_bits : im.sec_off[sec] * 8;
   LaneBits b;
-  b.Init(im.cs, im.cs_size, sec_bits);
+  b.Init(im.cs, im.cs_size, sec_bits, ring_base + si, (uint32_t)nslots);
   const uint32_t preset = b.Read(CeilLog2D((uint32_t)im.num_presets));
   const uint32_t nbc = im.num_block_ctx;
   const uint32_t ctx_offset = preset * nbc * 495;
   uint32_t err = preset >= (uint32_t)im.num_presets ? (uint32_t)kErrBitstream : 0u;
   uint32_t state = b.Read(32);
-  JXL_GLB uint8_t* const nz = G(im.nzmap) + (size_t)g * 3 * 1024;
-  const JXL_GLB uint32_t* const cellinfo = G(im.cellinfo);
-  const JXL_GLB uint16_t* const rawq = G(im.rawq);
   const int wp = im.wp;
-  const int n_qf = im.n_qf;
   const bool use_staged_orders = !im.custom_orders;
-  // cursor over 8x8 cells of the group
-  int bx = -1, by = 0;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const size_t group_px = (size_t)gy * kGroupDim * wp + (size_t)gx * kGroupDim;
+  // block descriptors: staged through a small LDS queue that is topped up together with the bit window
+  const JXL_GLB U2* const list = (const JXL_GLB U2*)G(im.blk_list + (size_t)g * 2048);
+  const uint32_t nblk = im.blk_count[g];
+  JXL_LDS U2* const dq = descq + si;
+  uint32_t bi = 0, dfilled = 0, it = 0;
   // current block
-  uint32_t lcx = 0, lcy = 0, log2c = 0, covered = 1, size = 64, ord = 0, lng_log2 = 3, qf_idx = 0;
+  uint32_t bx = 0, by = 0, lcx = 0, lcy = 0, log2c = 0, covered = 1, size = 64, ord = 0, lng_log2 = 3, ctxs = 0;
   bool transposed = true;
   size_t px0 = 0;
   // current (block, channel)
   int ci = 3;
-  uint32_t nzeros = 0, k = 0, prev = 0, histo = 0, block_ctx = 0;
-  const JXL_GLB uint16_t* gorder = nullptr;   // order table in global memory ...
-  uint32_t lorder = 0;                // ... or offset of a small natural order staged with the tables
-  bool order_staged = false;
+  uint32_t nzeros = 0, k = 0, prev = 0, histo = 0;
+  uint32_t lorder = 0;                        // offset of a small natural order staged with the tables ...
+  bool order_staged = false;                  // ... else the order table is read from global memory (blocks of 128 and up, custom orders)
+  uint32_t pnext = 0;                         // staged order entry of coefficient k, fetched one token ahead
   JXL_GLB int32_t* plane = nullptr;
+  // no global load may sit in the token loop (its wait would also wait for the stores): plane pointers up front
+  JXL_GLB int32_t* const coef0 = G(im.coef[0]);
+  JXL_GLB int32_t* const coef1 = G(im.coef[1]);
+  JXL_GLB int32_t* const coef2 = G(im.coef[2]);
   bool want_nz = true;
   while (!err) {
-    if (want_nz && ci >= 3) {
-      // advance to the next varblock (top-left cell) of this group
-      bool found = false;
-      for (;;) {
-        if (++bx >= bw) { bx = 0; by++; }
-        if (by >= bh) break;
-        const uint32_t info = cellinfo[(size_t)(by0 + by) * im.w8 + bx0 + bx];
-        if ((info & 0x8003FF00u) != 0x80000000u) continue;
-        const uint32_t s = info & 0xFF;
-        lcx = (info >> 18) & 7; lcy = (info >> 21) & 7;
-        log2c = lcx + lcy; covered = 1u << log2c; size = covered << 6;
-        ord = d_order_bucket[s];
-        lng_log2 = 3 + max(lcx, lcy);
-        transposed = !IsSpecialS(s) && lcy >= lcx;
-        const uint32_t rq = rawq[(size_t)(by0 + by) * im.w8 + bx0 + bx];
-        qf_idx = 0;
-        for (int i = 0; i < n_qf; i++) qf_idx += rq > im.qf_thr[i];
-        px0 = (size_t)(by0 + by) * 8 * wp + (size_t)(bx0 + bx) * 8;
-        found = true;
-        break;
+    if ((it++ & (kTopUpEvery - 1)) == 0) {
+      // a token consumes at most 48 bits and starts at most one block: 16 tokens never outrun 24 words / 6 descriptors
+      b.TopUp();
+      const uint32_t lim = min(nblk, bi + 8);
+      if (dfilled < lim) {
+        U2 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (dfilled + i < lim) dq[(size_t)((dfilled + i) & 7) * nslots] = v[i];
+        dfilled = lim;
       }
-      if (!found) break;
+    }
+    if (want_nz && ci >= 3) {
+      if (bi >= nblk) break;
+      const U2 d = dq[(size_t)(bi & 7) * nslots];
+      bi++;
+      bx = d.x & 31; by = (d.x >> 5) & 31;
+      const uint32_t s = (d.x >> 10) & 31;
+      lcx = (d.x >> 15) & 7; lcy = (d.x >> 18) & 7; ord = (d.x >> 21) & 15;
+      ctxs = d.y;
+      log2c = lcx + lcy; covered = 1u << log2c; size = covered << 6;
+      lng_log2 = 3 + max(lcx, lcy);
+      transposed = !IsSpecialS(s) && lcy >= lcx;
+      px0 = group_px + (size_t)by * 8 * wp + (size_t)bx * 8;
       ci = 0;
     }
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     uint32_t ctx;
     if (want_nz) {
-      const JXL_GLB uint8_t* row = nz + c * 1024 + by * 32;
+      JXL_LDS uint8_t* const cc = col + (size_t)(c * 32) * nslots;
       uint32_t predicted;
-      if (bx == 0) predicted = by == 0 ? 32 : row[-32];
-      else if (by == 0) predicted = row[bx - 1];
-      else predicted = ((uint32_t)row[-32 + bx] + row[bx - 1] + 1) >> 1;
-      const uint32_t cprime = c < 2 ? (c ^ 1) : 2;
-      block_ctx = im.block_ctx_map[(cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx];
+      if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)cc[0];
+      else if (by == 0) predicted = cc[(size_t)(bx - 1) * nslots];
+      else predicted = ((uint32_t)cc[(size_t)bx * nslots] + cc[(size_t)(bx - 1) * nslots] + 1) >> 1;
+      const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
       uint32_t nzc = predicted >= 64 ? 64 : predicted;
       nzc = nzc < 8 ? nzc : 4 + nzc / 2;
       ctx = ctx_offset + nzc * nbc + block_ctx;
@@ -763,24 +932,27 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
       nzeros = u;
       if (nzeros + covered > size) { err |= kErrBitstream; break; }
       const uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
-      JXL_GLB uint8_t* row = nz + c * 1024 + by * 32;
-      for (uint32_t iy = 0; iy < (1u << lcy); iy++)
-        for (uint32_t ix = 0; ix < (1u << lcx); ix++) row[iy * 32 + bx + ix] = fill;
+      JXL_LDS uint8_t* const cc = col + (size_t)(c * 32 + bx) * nslots;
+      for (uint32_t ix = 0; ix < (1u << lcx); ix++) cc[(size_t)ix * nslots] = fill;
       if (nzeros) {
+        const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
         histo = ctx_offset + nbc * 37 + 458 * block_ctx;
         order_staged = use_staged_orders && ord <= 8;
-        lorder = d_order_lds_off[ord <= 8 ? ord : 0];
-        gorder = G(im.order[ord * 3 + c]);
-        plane = G(im.coef[c]) + px0;
+        lorder = order_off[ord <= 8 ? ord : 0];
+        plane = (c == 0 ? coef0 : (c == 1 ? coef1 : coef2)) + px0;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
+        pnext = lds_orders[lorder + (order_staged ? k : 0u)];
         want_nz = false;
       } else {
         ci++;
       }
     } else {
+      uint32_t p = pnext;
+      const uint32_t k1 = k + 1 < size ? k + 1 : k;
+      pnext = lds_orders[lorder + (order_staged ? k1 : 0u)];
       if (u) {
-        const uint32_t p = order_staged ? (uint32_t)lds_orders[lorder + k] : (uint32_t)gorder[k];
+        if (!order_staged) p = G(im.order[ord * 3 + c])[k];   // rare; the only global load of the loop, waited for in this branch
         const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
         const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
         plane[(size_t)ky * wp + kx] = UnpackSigned(u);
@@ -799,90 +971,31 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   if (err) SetError(im, err);
 }
 
-// ------------------------------------------------------------------ alpha (Modular stream after the HF tokens)
-// Two mappings: lane_stride == 64 -> 64-thread workgroup = one section, split-phase decode by the whole wavefront;
-// otherwise 256-thread workgroups (one wavefront per SIMD of a CU), the first 64/lane_stride lanes of every
-// wavefront own one section each.
+// ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
+// One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds>
-__global__ __launch_bounds__(256) void alpha_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
+__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   if (!im.has_alpha || im.alpha_in_global) return;
-  CodeTab<kLds> tab;
-  typename AS<kLds>::Tree tree;
-  RowBuf<kLds> rbuf;
-  JXL_LDS int32_t* resid = nullptr;
-  const int per_wave = 64 / lane_stride;
-  const int slots = lane_stride == 64 ? 1 : 4 * per_wave;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slot = wave * per_wave + (lane < per_wave ? lane : 0);
-  if constexpr (kLds) {
-    JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
-    size_t off = 0;
-    rbuf.rb = (JXL_LDS int32_t*)lds + (lane_stride == 64 ? 0 : slot); off += (size_t)slots * 256 * 4;
-    rbuf.rb_stride = slots;
-    rbuf.rb_width = 256;
-    if (lane_stride == 64) { resid = (JXL_LDS int32_t*)(lds + off); off += 64 * 256 * 4; }
-    JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
-    for (int i = threadIdx.x; i < im.tree_size; i += blockDim.x) st[i] = ((const I4*)im.tree)[i];
-    tree = st;
-    StageCode(lds, off, im.mcode, tab, threadIdx.x, blockDim.x);
-    __syncthreads();
-  } else {
-    GlobalCode(im.mcode, tab);
-    tree = (const I4*)im.tree;
-    rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
-  }
-  if constexpr (kLds) {
-    if (lane_stride == 64) {
-      // one section per wavefront (blockDim == 64): split-phase decode by all 64 lanes when the stream allows it
-      __shared__ uint32_t s_fail;
-      const int g = task.first;
-      const uint64_t start = im.grp_bitpos[g];
-      if (start == ~(uint64_t)0) return;
-      const int gx = g % im.xg, gy = g / im.xg;
-      const int sec = 2 + im.nlf + g;
-      const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
-      const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
-      const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
-      DevTreeNode leaf;
-      bool wavepath = StaticLeaf<true>(tree, 0, sid, &leaf);
-      if (wavepath) { const uint32_t p = leaf.a & 0xFF; wavepath = p == 0 || p == 1 || p == 2 || p == 5; }
-      LaneBits b;
-      uint32_t state = 0;
-      if (threadIdx.x == 0) {
-        b.Init(im.cs, im.cs_size, start);
-        s_fail = b.Read(4) != 3 ? (uint32_t)kErrUnsupportedHeader : 0u;
-        state = b.Read(32);
-      }
-      __syncthreads();
-      if (s_fail) { if (threadIdx.x == 0) SetError(im, s_fail); return; }
-      int32_t* out = im.alpha32 + (size_t)y0 * im.w + x0;
-      if (wavepath) {
-        ModularChannelWave(b, state, tab, leaf, gw, gh, out, im.w, (JXL_LDS int32_t*)smem, resid, threadIdx.x);
-      } else if (threadIdx.x == 0) {
-        ModularChannel<true>(b, state, tab, tree, 0, sid, gw, gh, out, im.w, rbuf);
-      }
-      if (threadIdx.x == 0) {
-        uint32_t err = 0;
-        if (state != 0x130000u) err |= kErrBitstream;
-        if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
-        if (err) SetError(im, err);
-      }
-      return;
-    }
-  }
-  if (lane >= per_wave) return;   // the first per_wave lanes of every wavefront own one section each
-  const int si = lane_stride == 64 ? 0 : slot;
-  if (si >= task.count) return;
-  const int g = task.first + si;
+  ModTables<kLds> mt;
+  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  const int lane = threadIdx.x;
+  if (lane >= 64 / lane_stride || lane >= task.count) return;
+  const int g = task.first + lane;
+  ChanDesc* desc = im.alpha_desc + g;
   const uint64_t start = im.grp_bitpos[g];
-  if (start == ~(uint64_t)0) return;   // the HF decoder already reported the failure
+  if (start == ~(uint64_t)0) {   // the HF decoder already reported the failure
+    ChanDesc d;
+    d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
+    *desc = d;
+    return;
+  }
   const int gx = g % im.xg, gy = g / im.xg;
   const int sec = 2 + im.nlf + g;
   LaneBits b;
-  b.Init(im.cs, im.cs_size, start);
+  b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
   uint32_t err = 0;
   if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
   else {
@@ -890,11 +1003,42 @@ __global__ __launch_bounds__(256) void alpha_kernel(const DevImage* imgs, const 
     const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
     const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
     const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
-    ModularChannel(b, state, tab, tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, rbuf);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc);
     if (state != 0x130000u) err |= kErrBitstream;
     if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
-  if (err) SetError(im, err);
+  if (err) {
+    ChanDesc d;
+    d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
+    *desc = d;
+    SetError(im, err);
+  }
+}
+
+// Phase B: one wavefront per group: predictors (or plain conversion) -> 8-bit alpha plane.
+__global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) {
+  __shared__ int32_t s_carry[256];
+  const DevImage& im = imgs[blockIdx.y];
+  const int g = blockIdx.x;
+  if (!im.has_alpha || g >= im.ng) return;
+  const int lane = threadIdx.x;
+  const ChanDesc d = im.alpha_desc[g];
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
+  const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
+  int32_t* plane = im.alpha32 + (size_t)y0 * im.w + x0;
+  uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
+  const int sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  if (d.kind == kChanResid) {
+    PredictWave<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry, lane);
+  } else {
+    const bool cst = d.kind == kChanConst;
+    for (int i = lane; i < gw * gh; i += 64) {
+      const size_t o = (size_t)(i / gw) * im.w + (i % gw);
+      const int v = cst ? d.value : plane[o];
+      out[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+  }
 }
 
 // ------------------------------------------------------------------ launch wrappers
@@ -902,35 +1046,51 @@ static void RaiseLds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void LaunchLfGroups(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s) {
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s) {
   if (ntasks <= 0) return;
   if (lds_bytes) {
-    RaiseLds((const void*)lf_group_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(lf_group_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks);
+    RaiseLds((const void*)lf_ans_kernel<true>, lds_bytes);
+    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks);
   } else {
-    hipLaunchKernelGGL(lf_group_kernel<false>, dim3(ntasks), dim3(64), 0, s, imgs, tasks);
+    hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), 64 * kRingWords * 4, s, imgs, tasks);
   }
+}
+
+void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s) {
+  if (ntasks <= 0) return;
+  hipLaunchKernelGGL(lf_finish_kernel, dim3(ntasks), dim3(256), 0, s, imgs, tasks);
+}
+
+void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s) {
+  if (nimg <= 0 || max_groups <= 0) return;
+  hipLaunchKernelGGL(hf_blocklist_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes,
                     const uint16_t* natural_orders_small, hipStream_t s) {
   if (nwg <= 0) return;
+  const size_t col_bytes = (size_t)(4 * (64 / lane_stride)) * (96 + 64 + kRingWords * 4);
   if (lds_bytes) {
     RaiseLds((const void*)hf_decode_kernel<true>, lds_bytes);
     hipLaunchKernelGGL(hf_decode_kernel<true>, dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, natural_orders_small);
   } else {
-    hipLaunchKernelGGL(hf_decode_kernel<false>, dim3(nwg), dim3(256), 0, s, imgs, tasks, lane_stride, natural_orders_small);
+    hipLaunchKernelGGL(hf_decode_kernel<false>, dim3(nwg), dim3(256), col_bytes, s, imgs, tasks, lane_stride, natural_orders_small);
   }
 }
 
-void LaunchAlpha(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s) {
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s) {
   if (nwg <= 0) return;
   if (lds_bytes) {
-    RaiseLds((const void*)alpha_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(alpha_kernel<true>, dim3(nwg), dim3(lane_stride == 64 ? 64 : 256), lds_bytes, s, imgs, tasks, lane_stride);
+    RaiseLds((const void*)alpha_ans_kernel<true>, lds_bytes);
+    hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride);
   } else {
-    hipLaunchKernelGGL(alpha_kernel<false>, dim3(nwg), dim3(lane_stride == 64 ? 64 : 256), 0, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), 64 * kRingWords * 4, s, imgs, tasks, lane_stride);
   }
+}
+
+void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s) {
+  if (nimg <= 0 || max_groups <= 0) return;
+  hipLaunchKernelGGL(alpha_finish_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 
 }  // namespace jxlhip

@@ -6,13 +6,16 @@
 namespace jxlhip {
 
 // entropy_kernels.hip (lds_bytes == 0 selects the variant that keeps its tables in global memory)
-void LaunchLfGroups(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s);
+// LF groups: phase A (ANS, one lane per LF group, one wavefront per image chunk) and phase B (one workgroup per LF group)
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s);
+void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
+void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes,
                     const uint16_t* natural_orders_small, hipStream_t s);
-void LaunchAlpha(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
+void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
-void LaunchAlphaToU8(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,
                               const float* llf_scale, hipStream_t s);
 // tile_kernels.hip

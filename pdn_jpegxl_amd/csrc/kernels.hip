@@ -1,7 +1,7 @@
 // HIP kernels (gfx950) of the JPEG XL VarDCT decode path.
 //
 // Pixel-domain stages (the entropy-coded stages live in entropy_kernels.hip):
-//   lf_dequant / lf_smooth / cell_sigma / alpha_to_u8 / dequant / llf / idct_v / idct_h / idct_special
+//   lf_dequant / lf_smooth / cell_sigma / dequant / llf / idct_v / idct_h / idct_special
 //   gaborish / epf<stage> / xyb_to_out
 // DESIGN.md has the data layout and the per-kernel roofline.
 #include <hip/hip_runtime.h>
@@ -67,16 +67,6 @@ __global__ void cell_sigma_kernel(const DevImage* imgs) {
     float sigma = sigma_quant * im.epf_sharp_lut[im.sharp[i]];
     sigma = fminf(-1e-4f, sigma);
     im.inv_sigma[i] = 1.0f / sigma;
-  }
-}
-
-__global__ void alpha_to_u8_kernel(const DevImage* imgs) {
-  const DevImage& im = imgs[blockIdx.y];
-  if (!im.has_alpha) return;
-  const size_t n = (size_t)im.w * im.h;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int v = im.alpha32[i];
-    im.alpha[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
   }
 }
 
@@ -335,10 +325,6 @@ void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipSt
   hipLaunchKernelGGL(lf_dequant_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
   hipLaunchKernelGGL(lf_smooth_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
   hipLaunchKernelGGL(cell_sigma_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
-}
-
-void LaunchAlphaToU8(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s) {
-  hipLaunchKernelGGL(alpha_to_u8_kernel, Grid2(max_pixels, nimg), dim3(256), 0, s, imgs);
 }
 
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,

@@ -215,15 +215,20 @@ def load_image(data, fail_at=None):
     return img
 
 
-def save_image(bgra, distance=1.0, effort=7, lossless=False, exif=None, icc=None, xmp=None, progress=None):
-    """JpegXLNative.SaveImage: bgra = uint8 (h, w, 4) BGRA surface.  Returns the encoded bytes."""
+def save_image(bgra, distance=1.0, effort=7, lossless=False, exif=None, icc=None, xmp=None, progress=None, write_result=None):
+    """JpegXLNative.SaveImage: bgra = uint8 (h, w, 4) BGRA surface (rows may be strided).  Returns the encoded bytes.
+    write_result: HRESULT the Write callback returns instead of S_OK (failure injection)."""
     L = lib()
-    bgra = np.ascontiguousarray(bgra, dtype=np.uint8)
+    bgra = np.asarray(bgra, dtype=np.uint8)
+    if bgra.strides[2] != 1 or bgra.strides[1] != 4:
+        bgra = np.ascontiguousarray(bgra)
     h, w, _ = bgra.shape
     out = bytearray()
     pos = [0]
 
     def write(p, n):
+        if write_result is not None:
+            return write_result - (1 << 32) if write_result >= (1 << 31) else write_result
         chunk = C.string_at(p, n)
         end = pos[0] + n
         if end > len(out):

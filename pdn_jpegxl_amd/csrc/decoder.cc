@@ -897,13 +897,7 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
   return result;
 }
 
-EncoderStatus SaveImage(const BitmapData* bitmap, const EncoderOptions* options, const EncoderImageMetadata* metadata,
-                        IOCallbacks* callbacks, ErrorInfo* err, ProgressProc progress) {
-  if (!bitmap || !options || !callbacks || !metadata) return EncoderStatus_NullParameter;   // Encoder/JxlEncoder.cpp:155-158
-  if (progress && !progress(0)) return EncoderStatus_UserCanceled;                           // :162
-  SetErr(err, "SaveImage: the MI355X encode path is not built yet (decode path only in this round).");
-  return EncoderStatus_EncodeError;
-}
+// SaveImage lives in encoder.cc.
 
 }  // extern "C"
 

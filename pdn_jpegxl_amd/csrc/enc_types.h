@@ -1,0 +1,72 @@
+// Device-side description of one image being encoded (encode_kernels.hip / encoder.cc).
+#pragma once
+#include <stdint.h>
+#include "dev_types.h"
+
+namespace jxlhip {
+
+struct DevToken { uint32_t ctx, value; };   // after the reverse ANS pass `ctx` holds flushed << 16 | flush bits
+
+// leaf (= context) ids of the encoder's fixed MA tree, in decode order (encoder.cc: MakeEncoderTree)
+enum EncLeaf : uint32_t {
+  kLeafAlpha = 0, kLeafSharp = 1, kLeafAlphaGlobal = 2, kLeafCfl = 3, kLeafLfB = 4, kLeafQf = 5, kLeafStrategy = 6, kLeafLfX = 7,
+  kLeafLfY = 8, kNumEncLeaves = 9
+};
+constexpr uint32_t kEncSyms = 128;            // token alphabet of the fixed hybrid-uint config (4, 2, 0)
+constexpr uint32_t kAcContexts = 495 * 15;    // one preset, default block-context map
+constexpr uint32_t kLfTokCap = 3 * 65536;     // tokens per LF group: LF coefficients
+constexpr uint32_t kMetaTokCap = 65536;       // ... and quant-field row of the block info
+constexpr uint32_t kAcTokCap = 3 * 65 * 1024; // tokens per group: 1 + 64 per (block, channel)
+constexpr uint32_t kAlphaTokCap = 65536;
+
+struct EncCodeDev {
+  const uint8_t* ctx_map;
+  const uint16_t* freq;    // [cluster * kEncSyms + symbol]
+  const uint16_t* start;
+  const uint16_t* rmap;    // [cluster * 4096 + start + offset]
+  uint32_t num_clusters, pad;
+};
+
+struct EncImage {
+  int32_t w, h, w8, h8, wp, hp;
+  int32_t xg, yg, ng, xlf, ylf, nlf;
+  int32_t gray, has_alpha, gab, lossless;
+  // source (host layout BitmapData: BGRA8, `stride` bytes per row)
+  const uint8_t* bgra;
+  int32_t stride, pad0;
+  uint32_t* flags;          // [0] some pixel is not gray, [1] some pixel has alpha < 255
+  // planes
+  float* xyb[3];            // w*h
+  float* pad[3];            // wp*hp: (inverse-Gaborish sharpened) XYB, edge-replicated to whole 8x8 cells
+  int32_t* alpha_px;        // w*h
+  int32_t* lfq[3];          // w8*h8 quantised LF (X, Y, B)
+  int32_t* rawq;            // w8*h8 raw quant field (1..256)
+  int32_t* qs[3];           // w8*h8*64 quantised coefficients in scan order
+  uint8_t* nz[3];           // per cell: number of non-zero HF coefficients
+  uint8_t* last[3];         // per cell: scan position of the last non-zero coefficient (0: none)
+  // quantiser
+  float inv_mul_lf[3];      // 1 / (m_lf * inv_global_scale / quant_lf)
+  float mul_lf_y;           // LF dequant step of Y (chroma-from-luma of the LF uses the dequantised Y)
+  float inv_gs;             // 65536 / global_scale
+  float x_dm, b_dm;         // 0.8 ^ (x_qm_scale - 2), 0.8 ^ (b_qm_scale - 2)
+  float qbias1, qbias3;     // quantisation bias of |q| == 1 (Y) and the 1/q term
+  float gab_w[3][3];
+  const uint16_t* order8;   // natural order of the 8x8 DCT (scan position -> stored index kx * 8 + ky)
+  const float* dq8;         // 3 * 64 dequantisation multipliers (stored layout)
+  const float* basis8;      // B[k * 8 + n]
+  // tokens
+  DevToken* tok_lf;         // [nlf][kLfTokCap]
+  DevToken* tok_meta;       // [nlf][kMetaTokCap]
+  DevToken* tok_ac;         // [ng][kAcTokCap]
+  DevToken* tok_alpha;      // [ng][kAlphaTokCap]
+  uint32_t* n_ac;           // [ng]
+  uint32_t* hist_mod;       // [kNumEncLeaves][kEncSyms]
+  uint32_t* hist_ac;        // [kAcContexts][kEncSyms]
+  // entropy coding
+  EncCodeDev mcode, acode;
+  uint8_t* sec_bytes;       // section s at s * sec_cap
+  uint64_t* sec_bits;       // bits written per section
+  uint64_t sec_cap;
+};
+
+}  // namespace jxlhip

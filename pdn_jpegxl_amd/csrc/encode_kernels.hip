@@ -1,0 +1,486 @@
+// HIP kernels (gfx950) of the encode path behind SaveImage (reference: Encoder/JxlEncoder.cpp:33-144, the
+// arithmetic it delegates to JxlEncoderAddImageFrame :128).
+//
+//   enc_analyze_kernel        GetOutputPixelFormat (:33-77): is every pixel gray / opaque?                 (reduction)
+//   enc_xyb_kernel            PixelFormatConversion (BGRA -> channels) + sRGB -> linear -> XYB              (elementwise)
+//   enc_sharpen_pad_kernel    inverse-Gaborish pre-sharpening, edge replication to whole 8x8 cells          (3x3 stencil)
+//   enc_block_kernel          one wavefront per 8x8 block: DCT, adaptive quant field, LF + HF quantisation
+//                             with chroma from luma, coefficients in scan order, non-zero statistics
+//   enc_*_tokens_kernel       context modelling: (context, value) tokens + histograms, all data-parallel
+//   enc_sections_kernel       ANS coding, one lane per section (reverse pass for the state, forward pass for the bits)
+#include <hip/hip_runtime.h>
+#include "enc_types.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+namespace {
+
+__device__ __forceinline__ uint32_t PackSignedD(int32_t v) { return v >= 0 ? (uint32_t)v << 1 : (((uint32_t)(-(int64_t)v)) << 1) - 1; }
+__device__ __forceinline__ int CeilLog2E(uint32_t x) { return x <= 1 ? 0 : 32 - __clz(x - 1); }
+__device__ __forceinline__ int MirrorE(int v, int n) {
+  while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
+  return v;
+}
+// hybrid-uint token of `v` under the config (split_exponent 4, msb_in_token 2, lsb_in_token 0)
+__device__ __forceinline__ void HybridD(uint32_t v, uint32_t* tok, uint32_t* nbits, uint32_t* bits) {
+  if (v < 16) { *tok = v; *nbits = 0; *bits = 0; return; }
+  const uint32_t n = 31 - __clz(v), m = v - (1u << n);
+  *tok = 16 + ((n - 4) << 2) + (m >> (n - 2));
+  *nbits = n - 2;
+  *bits = m & ((1u << (n - 2)) - 1);
+}
+__device__ __forceinline__ int32_t GradientPred(int32_t W, int32_t N, int32_t NW) {
+  const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
+  return (int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
+}
+
+__device__ const uint8_t e_nnz_ctx[64] = {0,   0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152, 152, 152, 152, 152, 152, 180,
+                                          180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
+                                          206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
+
+}  // namespace
+
+// ------------------------------------------------------------------ pixel format analysis (Encoder/JxlEncoder.cpp:33-77)
+__global__ void enc_analyze_kernel(EncImage im) {
+  uint32_t notgray = 0, alpha = 0;
+  const size_t n = (size_t)im.w * im.h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % im.w), y = (int)(i / im.w);
+    const uchar4 p = *(const uchar4*)(im.bgra + (size_t)y * im.stride + (size_t)x * 4);   // B, G, R, A
+    notgray |= (p.x != p.y) | (p.y != p.z);
+    alpha |= p.w < 255;
+  }
+  if (__any(notgray) && (threadIdx.x & 63) == 0) atomicOr(&im.flags[0], 1u);
+  if (__any(alpha) && (threadIdx.x & 63) == 0) atomicOr(&im.flags[1], 1u);
+}
+
+// ------------------------------------------------------------------ BGRA8 -> XYB (+ alpha plane)
+// Channel selection as PixelFormatConversion.cpp:16-121 (gray takes the B channel); sRGB decoding, opsin absorbance.
+__global__ void enc_xyb_kernel(EncImage im) {
+  const size_t n = (size_t)im.w * im.h;
+  const float kM[9] = {0.30f, 0.622f, 0.078f, 0.23f, 0.692f, 0.078f, 0.24342268924547819f, 0.20476744424496821f, 0.55180986650955360f};
+  const float kB = 0.0037930732552754493f;
+  const float cb = cbrtf(kB);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % im.w), y = (int)(i / im.w);
+    const uchar4 p = *(const uchar4*)(im.bgra + (size_t)y * im.stride + (size_t)x * 4);
+    const uint8_t r8 = im.gray ? p.x : p.z, g8 = im.gray ? p.x : p.y, b8 = p.x;
+    auto lin = [](uint8_t v8) {
+      const float v = (float)v8 * (1.0f / 255.0f);
+      return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f);
+    };
+    const float r = lin(r8), g = lin(g8), b = lin(b8);
+    float mr = kM[0] * r + kM[1] * g + kM[2] * b + kB;
+    float mg = kM[3] * r + kM[4] * g + kM[5] * b + kB;
+    float mb = kM[6] * r + kM[7] * g + kM[8] * b + kB;
+    mr = fmaxf(mr, 0.f); mg = fmaxf(mg, 0.f); mb = fmaxf(mb, 0.f);
+    const float gr = cbrtf(mr) - cb, gg = cbrtf(mg) - cb, gb = cbrtf(mb) - cb;
+    im.xyb[0][i] = 0.5f * (gr - gg);
+    im.xyb[1][i] = 0.5f * (gr + gg);
+    im.xyb[2][i] = gb;
+    if (im.has_alpha) im.alpha_px[i] = p.w;
+  }
+}
+
+// ------------------------------------------------------------------ 2*I - Gaborish, padded to whole cells
+__global__ void enc_sharpen_pad_kernel(EncImage im) {
+  const size_t n = (size_t)im.wp * im.hp;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = min((int)(i % im.wp), im.w - 1), y = min((int)(i / im.wp), im.h - 1);
+    const int xl = MirrorE(x - 1, im.w), xr = MirrorE(x + 1, im.w), yt = MirrorE(y - 1, im.h), yb = MirrorE(y + 1, im.h);
+    for (int c = 0; c < 3; c++) {
+      const float* p = im.xyb[c];
+      const float v = p[(size_t)y * im.w + x];
+      float o = v;
+      if (im.gab) {
+        const float* t = p + (size_t)yt * im.w;
+        const float* m = p + (size_t)y * im.w;
+        const float* b = p + (size_t)yb * im.w;
+        const float blur = m[x] * im.gab_w[c][0] + (t[x] + b[x] + m[xl] + m[xr]) * im.gab_w[c][1] + (t[xl] + t[xr] + b[xl] + b[xr]) * im.gab_w[c][2];
+        o = 2.0f * v - blur;
+      }
+      im.pad[c][i] = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ one wavefront per 8x8 block
+// lane = scan position.  Forward DCT as two 8-point passes through LDS, activity -> raw quant, LF and HF quantisation.
+__global__ __launch_bounds__(256) void enc_block_kernel(EncImage im) {
+  __shared__ float s_px[4][3][64];
+  __shared__ float s_t[4][3][64];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int cell = blockIdx.x * 4 + wv;
+  const int ncell = im.w8 * im.h8;
+  const bool live = cell < ncell;
+  const int bx = live ? cell % im.w8 : 0, by = live ? cell / im.w8 : 0;
+  const int py = lane >> 3, pxx = lane & 7;
+  float pix[3];
+  for (int c = 0; c < 3; c++) {
+    pix[c] = im.pad[c][(size_t)(by * 8 + py) * im.wp + bx * 8 + pxx];
+    s_px[wv][c][lane] = pix[c];
+  }
+  __syncthreads();
+  // vertical pass: t[ky][x] = 1/8 sum_y px[y][x] B[ky][y]   (this lane: ky = py, x = pxx)
+  for (int c = 0; c < 3; c++) {
+    float a = 0.f;
+    for (int y = 0; y < 8; y++) a += s_px[wv][c][y * 8 + pxx] * im.basis8[py * 8 + y];
+    s_t[wv][c][lane] = a * 0.125f;
+  }
+  __syncthreads();
+  const uint32_t p = im.order8[lane];          // stored index kx * 8 + ky
+  const int kx = p >> 3, ky = p & 7;
+  float coef[3];
+  for (int c = 0; c < 3; c++) {
+    float a = 0.f;
+    for (int x = 0; x < 8; x++) a += s_t[wv][c][ky * 8 + x] * im.basis8[kx * 8 + x];
+    coef[c] = a * 0.125f;
+  }
+  // activity of Y -> raw quant (finer steps in flat areas)
+  float s = pix[1], s2 = pix[1] * pix[1];
+  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
+  const float mean = s * (1.0f / 64), var = fmaxf(0.f, s2 * (1.0f / 64) - mean * mean);
+  const float act = sqrtf(var);
+  const float mod = 0.7f + 0.8f / (1.0f + act / 0.012f);
+  int q = (int)rintf(16.0f * mod);
+  q = max(1, min(256, q));
+  if (!live) return;
+  if (lane == 0) {
+    im.rawq[cell] = q;
+    // LF: Y first; X and B code the residual after the LF chroma-from-luma (base correlation 0 for X, 1 for B)
+    const int32_t qy = (int32_t)rintf(coef[1] * im.inv_mul_lf[1]);
+    const float fy = (float)qy * im.mul_lf_y;
+    im.lfq[1][cell] = qy;
+    im.lfq[0][cell] = (int32_t)rintf(coef[0] * im.inv_mul_lf[0]);
+    im.lfq[2][cell] = (int32_t)rintf((coef[2] - fy) * im.inv_mul_lf[2]);
+  }
+  const float scale = im.inv_gs / (float)q;
+  const float dqs[3] = {scale * im.x_dm, scale, scale * im.b_dm};
+  int32_t qi[3] = {0, 0, 0};
+  float yd = 0.f;
+  if (lane >= 1) {
+    const float wy = im.dq8[64 + p];
+    const float vy = coef[1] / (dqs[1] * wy);
+    qi[1] = fabsf(vy) < 0.6f ? 0 : (int32_t)rintf(vy);
+    const float adj = qi[1] == 0 ? 0.f : (abs(qi[1]) == 1 ? (qi[1] > 0 ? im.qbias1 : -im.qbias1) : (float)qi[1] - im.qbias3 / (float)qi[1]);
+    yd = adj * dqs[1] * wy;
+    const float vx = coef[0] / (dqs[0] * im.dq8[p]);
+    qi[0] = fabsf(vx) < 0.6f ? 0 : (int32_t)rintf(vx);
+    const float vb = (coef[2] - yd) / (dqs[2] * im.dq8[128 + p]);
+    qi[2] = fabsf(vb) < 0.6f ? 0 : (int32_t)rintf(vb);
+  }
+  for (int c = 0; c < 3; c++) {
+    im.qs[c][(size_t)cell * 64 + lane] = qi[c];
+    const uint64_t m = __ballot(qi[c] != 0);
+    if (lane == 0) {
+      im.nz[c][cell] = (uint8_t)__popcll(m);
+      im.last[c][cell] = m ? (uint8_t)(63 - __clzll((long long)m)) : 0;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ tokens: LF coefficients (gradient predictor)
+__global__ __launch_bounds__(256) void enc_lf_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_h[3 * kEncSyms];
+  for (int i = threadIdx.x; i < 3 * (int)kEncSyms; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const int g = blockIdx.y;
+  const int gx = g % im.xlf, gy = g / im.xlf;
+  const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
+  const int bw = min(kLfGroupBlocks, im.w8 - bx0), bh = min(kLfGroupBlocks, im.h8 - by0);
+  const int n = 3 * bw * bh;
+  DevToken* out = im.tok_lf + (size_t)g * kLfTokCap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int mc = i / (bw * bh), r = i % (bw * bh), y = r / bw, x = r % bw;
+    const int c = mc == 0 ? 1 : (mc == 1 ? 0 : 2);   // modular channel order Y, X, B
+    const int32_t* pl = im.lfq[c] + (size_t)by0 * im.w8 + bx0;
+    const int32_t v = pl[(size_t)y * im.w8 + x];
+    int32_t W, N, NW;
+    if (x == 0) { W = y ? pl[(size_t)(y - 1) * im.w8] : 0; N = W; NW = W; }
+    else {
+      W = pl[(size_t)y * im.w8 + x - 1];
+      N = y ? pl[(size_t)(y - 1) * im.w8 + x] : W;
+      NW = y ? pl[(size_t)(y - 1) * im.w8 + x - 1] : W;
+    }
+    const uint32_t val = PackSignedD(v - GradientPred(W, N, NW));
+    DevToken t;
+    t.ctx = mc == 0 ? kLeafLfY : (mc == 1 ? kLeafLfX : kLeafLfB);
+    t.value = val;
+    out[i] = t;
+    uint32_t tok, nb, bits;
+    HybridD(val, &tok, &nb, &bits);
+    atomicAdd(&s_h[mc * kEncSyms + tok], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * (int)kEncSyms; i += 256) {
+    const uint32_t leaf = i / kEncSyms == 0 ? kLeafLfY : (i / kEncSyms == 1 ? kLeafLfX : kLeafLfB);
+    if (s_h[i]) atomicAdd(&im.hist_mod[leaf * kEncSyms + (i % kEncSyms)], s_h[i]);
+  }
+}
+
+// quant-field row of the block info (every cell is one 8x8 block): West predictor
+__global__ __launch_bounds__(256) void enc_meta_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_h[kEncSyms];
+  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const int g = blockIdx.y;
+  const int gx = g % im.xlf, gy = g / im.xlf;
+  const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
+  const int bw = min(kLfGroupBlocks, im.w8 - bx0), bh = min(kLfGroupBlocks, im.h8 - by0);
+  const int n = bw * bh;
+  DevToken* out = im.tok_meta + (size_t)g * kMetaTokCap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    auto at = [&](int k) { return im.rawq[(size_t)(by0 + k / bw) * im.w8 + bx0 + k % bw] - 1; };
+    // row 1 of a (count x 2) channel: West is the previous entry; for the first entry it is the sample above = strategy 0
+    const int32_t v = at(i), W = i ? at(i - 1) : 0;
+    DevToken t;
+    t.ctx = kLeafQf;
+    t.value = PackSignedD(v - W);
+    out[i] = t;
+    uint32_t tok, nb, bits;
+    HybridD(t.value, &tok, &nb, &bits);
+    atomicAdd(&s_h[tok], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256)
+    if (s_h[i]) atomicAdd(&im.hist_mod[kLeafQf * kEncSyms + i], s_h[i]);
+}
+
+// alpha: one lossless Modular channel per group, gradient predictor
+__global__ __launch_bounds__(256) void enc_alpha_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_h[kEncSyms];
+  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const int g = blockIdx.y;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
+  const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
+  const int n = gw * gh;
+  DevToken* out = im.tok_alpha + (size_t)g * kAlphaTokCap;
+  const int32_t* pl = im.alpha_px + (size_t)y0 * im.w + x0;
+  const uint32_t leaf = im.ng == 1 ? kLeafAlphaGlobal : kLeafAlpha;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int y = i / gw, x = i % gw;
+    const int32_t v = pl[(size_t)y * im.w + x];
+    int32_t W, N, NW;
+    if (x == 0) { W = y ? pl[(size_t)(y - 1) * im.w] : 0; N = W; NW = W; }
+    else {
+      W = pl[(size_t)y * im.w + x - 1];
+      N = y ? pl[(size_t)(y - 1) * im.w + x] : W;
+      NW = y ? pl[(size_t)(y - 1) * im.w + x - 1] : W;
+    }
+    DevToken t;
+    t.ctx = leaf;
+    t.value = PackSignedD(v - GradientPred(W, N, NW));
+    out[i] = t;
+    uint32_t tok, nb, bits;
+    HybridD(t.value, &tok, &nb, &bits);
+    atomicAdd(&s_h[tok], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256)
+    if (s_h[i]) atomicAdd(&im.hist_mod[leaf * kEncSyms + i], s_h[i]);
+}
+
+// ------------------------------------------------------------------ tokens: HF coefficients of one group
+// Token counts per (block, channel) are known from the block kernel, so an exclusive scan gives every (block, channel)
+// its slot and all of them are tokenised in parallel.
+__global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_cnt[3072];
+  __shared__ uint32_t s_part[256];
+  const int g = blockIdx.x;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
+  const int bw = min(kGroupBlocks, im.w8 - bx0), bh = min(kGroupBlocks, im.h8 - by0);
+  const int nent = bw * bh * 3;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 3072; e += 256) {
+    uint32_t cnt = 0;
+    if (e < nent) {
+      const int blk = e / 3, ci = e % 3, c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+      const size_t cell = (size_t)(by0 + blk / bw) * im.w8 + bx0 + blk % bw;
+      cnt = 1u + im.last[c][cell];
+    }
+    s_cnt[e] = cnt;
+  }
+  __syncthreads();
+  uint32_t mine = 0;
+  for (int k = 0; k < 12; k++) mine += s_cnt[tid * 12 + k];
+  s_part[tid] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (int i = 0; i < 256; i++) { const uint32_t v = s_part[i]; s_part[i] = acc; acc += v; }
+    im.n_ac[g] = acc;
+  }
+  __syncthreads();
+  DevToken* out = im.tok_ac + (size_t)g * kAcTokCap;
+  uint32_t pos = s_part[tid];
+  const uint32_t nbc = 15;
+  for (int k = 0; k < 12; k++) {
+    const int e = tid * 12 + k;
+    if (e >= nent) break;
+    const int blk = e / 3, ci = e % 3, c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    const int bx = blk % bw, by = blk / bw;
+    const size_t cell = (size_t)(by0 + by) * im.w8 + bx0 + bx;
+    const uint8_t* nzp = im.nz[c];
+    const uint32_t nzeros0 = nzp[cell];
+    uint32_t predicted;
+    if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)nzp[cell - im.w8];
+    else if (by == 0) predicted = nzp[cell - 1];
+    else predicted = ((uint32_t)nzp[cell - im.w8] + nzp[cell - 1] + 1) >> 1;
+    const uint32_t block_ctx = c == 1 ? 0u : 7u;   // default block-context map, 8x8 DCT: Y -> 0, X and B -> 7
+    uint32_t nzc = predicted >= 64 ? 64 : predicted;
+    nzc = nzc < 8 ? nzc : 4 + nzc / 2;
+    DevToken t;
+    t.ctx = nzc * nbc + block_ctx;
+    t.value = nzeros0;
+    out[pos++] = t;
+    uint32_t tok, nb, bits;
+    HybridD(t.value, &tok, &nb, &bits);
+    atomicAdd(&im.hist_ac[(size_t)t.ctx * kEncSyms + tok], 1u);
+    if (!nzeros0) continue;
+    const uint32_t histo = nbc * 37 + 458 * block_ctx;
+    const int32_t* q = im.qs[c] + cell * 64;
+    uint32_t nzeros = nzeros0, prev = nzeros0 > 4 ? 0u : 1u;   // size / 16 = 4
+    const uint32_t lastk = im.last[c][cell];
+    for (uint32_t kk = 1; kk <= lastk; kk++) {
+      const uint32_t fctx = kk < 16 ? kk - 1 : (kk < 32 ? 15 + ((kk - 16) >> 1) : 23 + ((kk - 32) >> 2));
+      t.ctx = histo + ((uint32_t)e_nnz_ctx[nzeros] + fctx) * 2 + prev;
+      t.value = PackSignedD(q[kk]);
+      out[pos++] = t;
+      HybridD(t.value, &tok, &nb, &bits);
+      atomicAdd(&im.hist_ac[(size_t)t.ctx * kEncSyms + tok], 1u);
+      prev = t.value != 0;
+      nzeros -= prev;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ANS coding, one lane per section
+namespace {
+
+struct LaneWriter {
+  uint32_t* out;
+  uint64_t acc;
+  int n;
+  uint64_t words;
+  __device__ void Init(uint8_t* p) { out = (uint32_t*)p; acc = 0; n = 0; words = 0; }
+  __device__ __forceinline__ void Put(int nbits, uint32_t v) {   // nbits <= 32
+    if (!nbits) return;
+    acc |= (uint64_t)(nbits == 32 ? v : (v & ((1u << nbits) - 1))) << n;
+    n += nbits;
+    if (n >= 32) { out[words++] = (uint32_t)acc; acc >>= 32; n -= 32; }
+  }
+  __device__ uint64_t Finish() {   // returns the bit count, pads the last word with zeros
+    const uint64_t bits = words * 32 + n;
+    if (n) out[words++] = (uint32_t)acc;
+    return bits;
+  }
+};
+
+// rANS with 12-bit precision and 16-bit renormalisation.  The decoder consumes the stream front to back, so the state
+// is run over the tokens back to front (recording what each step flushes), then the bits are laid out front to back.
+__device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, LaneWriter& w) {
+  uint32_t state = 0x130000u;
+  for (uint32_t r = n; r-- > 0;) {
+    const uint32_t cl = code.ctx_map[tok[r].ctx];
+    uint32_t sym, nb, bits;
+    HybridD(tok[r].value, &sym, &nb, &bits);
+    const uint32_t freq = code.freq[cl * kEncSyms + sym];
+    uint32_t flush = 0;
+    if ((state >> 20) >= freq) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
+    const uint32_t qd = state / freq, rm = state - qd * freq;
+    state = (qd << 12) + code.rmap[(size_t)cl * 4096 + code.start[cl * kEncSyms + sym] + rm];
+    tok[r].ctx = flush;
+  }
+  w.Put(32, state);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t flush = tok[i].ctx;
+    uint32_t sym, nb, bits;
+    HybridD(tok[i].value, &sym, &nb, &bits);
+    if (flush) w.Put(16, flush & 0xFFFF);
+    w.Put((int)nb, bits);
+  }
+}
+
+}  // namespace
+
+// sections [0, nlf): LF groups; [nlf, nlf + ng): pass groups
+__global__ __launch_bounds__(64) void enc_sections_kernel(EncImage im) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= im.nlf + im.ng) return;
+  LaneWriter w;
+  w.Init(im.sec_bytes + (size_t)s * im.sec_cap);
+  if (s < im.nlf) {
+    const int g = s;
+    const int gx = g % im.xlf, gy = g / im.xlf;
+    const int bw = min(kLfGroupBlocks, im.w8 - gx * kLfGroupBlocks), bh = min(kLfGroupBlocks, im.h8 - gy * kLfGroupBlocks);
+    w.Put(2, 0);   // extra_precision
+    w.Put(4, 3);   // modular group header: global tree, default weighted-predictor parameters, no transforms
+    EncodeStream(im.tok_lf + (size_t)g * kLfTokCap, (uint32_t)(3 * bw * bh), im.mcode, w);
+    w.Put(CeilLog2E((uint32_t)(bw * bh)), (uint32_t)(bw * bh - 1));   // number of varblocks - 1
+    w.Put(4, 3);
+    EncodeStream(im.tok_meta + (size_t)g * kMetaTokCap, (uint32_t)(bw * bh), im.mcode, w);
+  } else {
+    const int g = s - im.nlf;
+    EncodeStream(im.tok_ac + (size_t)g * kAcTokCap, im.n_ac[g], im.acode, w);
+    if (im.has_alpha && im.ng > 1) {
+      const int gx = g % im.xg, gy = g / im.xg;
+      const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
+      w.Put(4, 3);
+      EncodeStream(im.tok_alpha + (size_t)g * kAlphaTokCap, (uint32_t)(gw * gh), im.mcode, w);
+    }
+  }
+  im.sec_bits[s] = w.Finish();
+}
+
+// single-group frames carry their alpha in the global Modular section: coded on its own (section index nlf + ng)
+__global__ void enc_global_alpha_kernel(EncImage im) {
+  if (threadIdx.x || blockIdx.x) return;
+  LaneWriter w;
+  const int s = im.nlf + im.ng;
+  w.Init(im.sec_bytes + (size_t)s * im.sec_cap);
+  EncodeStream(im.tok_alpha, (uint32_t)(im.w * im.h), im.mcode, w);
+  im.sec_bits[s] = w.Finish();
+}
+
+// gathers the used bytes of every section into one contiguous buffer
+__global__ void enc_compact_kernel(EncImage im, const uint64_t* dst_off, uint8_t* dst, int nsec) {
+  const int s = blockIdx.y;
+  if (s >= nsec) return;
+  const uint64_t nbytes = (im.sec_bits[s] + 7) >> 3;
+  const uint8_t* src = im.sec_bytes + (size_t)s * im.sec_cap;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (uint64_t)gridDim.x * blockDim.x) dst[dst_off[s] + i] = src[i];
+}
+
+// ------------------------------------------------------------------ launch wrappers
+static inline unsigned GridFor(size_t work, unsigned cap = 8192) {
+  size_t b = (work + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+void LaunchEncAnalyze(const EncImage& im, hipStream_t s) {
+  hipLaunchKernelGGL(enc_analyze_kernel, dim3(GridFor((size_t)im.w * im.h, 2048)), dim3(256), 0, s, im);
+}
+void LaunchEncFrontEnd(const EncImage& im, hipStream_t s) {
+  hipLaunchKernelGGL(enc_xyb_kernel, dim3(GridFor((size_t)im.w * im.h)), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_sharpen_pad_kernel, dim3(GridFor((size_t)im.wp * im.hp)), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_block_kernel, dim3((unsigned)((im.w8 * im.h8 + 3) / 4)), dim3(256), 0, s, im);
+}
+void LaunchEncTokens(const EncImage& im, hipStream_t s) {
+  hipLaunchKernelGGL(enc_lf_tokens_kernel, dim3(64, im.nlf), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_meta_tokens_kernel, dim3(32, im.nlf), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_ac_tokens_kernel, dim3(im.ng), dim3(256), 0, s, im);
+  if (im.has_alpha) hipLaunchKernelGGL(enc_alpha_tokens_kernel, dim3(32, im.ng), dim3(256), 0, s, im);
+}
+void LaunchEncSections(const EncImage& im, hipStream_t s) {
+  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + 63) / 64)), dim3(64), 0, s, im);
+  if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
+}
+void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s) {
+  hipLaunchKernelGGL(enc_compact_kernel, dim3(64, nsec), dim3(256), 0, s, im, dst_off, dst, nsec);
+}
+
+}  // namespace jxlhip

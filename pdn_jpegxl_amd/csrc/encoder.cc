@@ -1,0 +1,386 @@
+// Host orchestration of the HIP encode path behind SaveImage (include/jxlfiletypeio.h).
+//
+// Mirrors EncoderWriteImage (reference: src/JxlFileTypeIO/Encoder/JxlEncoder.cpp:147-392): parameter checks (:155-158),
+// progress / cancellation checkpoints (:79-89,162,169,242,253,312,340-344,362), pixel-format analysis (:33-77),
+// channel conversion (PixelFormatConversion.cpp:16-121), container output with Exif / XMP boxes (:201,284-310) through
+// the host's Write callback in chunks of at most 64 KiB (OutputProcessor.cpp:16,87,134-151).  The arithmetic the
+// reference delegates to libjxl (JxlEncoderAddImageFrame :128, JxlEncoderFlushInput :367) runs in encode_kernels.hip.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/jxlfiletypeio.h"
+#include "enc_types.h"
+#include "host_parse.h"
+#include "host_write.h"
+#include "kernels.h"
+
+namespace jxlhip {
+
+void LaunchEncAnalyze(const EncImage& im, hipStream_t s);
+void LaunchEncFrontEnd(const EncImage& im, hipStream_t s);
+void LaunchEncTokens(const EncImage& im, hipStream_t s);
+void LaunchEncSections(const EncImage& im, hipStream_t s);
+void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s);
+
+namespace {
+
+struct EncFail : std::runtime_error {
+  EncoderStatus status;
+  EncFail(EncoderStatus st, const std::string& m) : std::runtime_error(m), status(st) {}
+};
+#define ENC_HIP(expr)                                                                                                   \
+  do {                                                                                                                  \
+    hipError_t e_ = (expr);                                                                                             \
+    if (e_ == hipErrorOutOfMemory) throw EncFail(EncoderStatus_OutOfMemory, "out of device memory");                    \
+    if (e_ != hipSuccess) throw EncFail(EncoderStatus_EncodeError, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+  } while (0)
+
+void SetEncErr(ErrorInfo* e, const char* msg) {
+  if (!e || !msg) return;
+  size_t n = strlen(msg);
+  if (n == 0) return;
+  if (n > 255) n = 255;
+  memcpy(e->errorMessage, msg, n);
+  e->errorMessage[n] = 0;
+}
+
+// device allocations of one SaveImage call
+struct Arena {
+  std::vector<void*> ptrs;
+  ~Arena() { for (void* p : ptrs) (void)hipFree(p); }
+  template <class T> T* Get(size_t count, bool zero = false) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    ENC_HIP(hipMalloc(&p, bytes));
+    ptrs.push_back(p);
+    if (zero) ENC_HIP(hipMemset(p, 0, bytes));
+    return (T*)p;
+  }
+  template <class T> T* Upload(const std::vector<T>& v) {
+    T* p = Get<T>(std::max<size_t>(v.size(), 1));
+    if (!v.empty()) ENC_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return p;
+  }
+};
+
+void Progress(ProgressProc progress, int percent) {
+  if (progress && !progress(percent)) throw EncFail(EncoderStatus_UserCanceled, "");   // Encoder/JxlEncoder.cpp:79-89
+}
+
+// The fixed MA tree of this encoder, in decode (breadth-first) order; leaf order = context ids of EncLeaf.
+std::vector<EncTreeNode> MakeEncoderTree(uint32_t nlf) {
+  auto split = [](int prop, int32_t v) { return EncTreeNode{prop, v, 0, 0, 1}; };
+  auto leaf = [](int pred, int32_t offset = 0) { return EncTreeNode{-1, 0, pred, offset, 1}; };
+  std::vector<EncTreeNode> t;
+  t.push_back(split(1, (int32_t)(3 * nlf + kNumQuantTables)));   // 0: stream > LF + metadata + quant-table streams ? alpha : 2
+  t.push_back(leaf(5));                                          // 1: alpha of a pass group              (kLeafAlpha)
+  t.push_back(split(1, (int32_t)(2 * nlf)));                     // 2: HF metadata (3) : 4
+  t.push_back(split(0, 2));                                      // 3: channel 3 = sharpness (5) : 6
+  t.push_back(split(1, 0));                                      // 4: LF coefficients (7) : global alpha (8)
+  t.push_back(leaf(0, 4));                                       // 5: EPF sharpness, constant 4            (kLeafSharp)
+  t.push_back(split(0, 1));                                      // 6: channel 2 = block info (9) : chroma-from-luma maps (10)
+  t.push_back(split(0, 1));                                      // 7: channel 2 = B (11) : 12
+  t.push_back(leaf(5));                                          // 8: alpha coded in the global section   (kLeafAlphaGlobal)
+  t.push_back(split(2, 0));                                      // 9: row 1 = quant field (13) : row 0 = strategies (14)
+  t.push_back(leaf(0));                                          // 10: chroma-from-luma maps, constant 0   (kLeafCfl)
+  t.push_back(leaf(5));                                          // 11: LF of B                            (kLeafLfB)
+  t.push_back(split(0, 0));                                      // 12: channel 1 = X (15) : channel 0 = Y (16)
+  t.push_back(leaf(1));                                          // 13: quant field row, West predictor    (kLeafQf)
+  t.push_back(leaf(0));                                          // 14: strategy row, constant 0 (DCT8)    (kLeafStrategy)
+  t.push_back(leaf(5));                                          // 15: LF of X                            (kLeafLfX)
+  t.push_back(leaf(5));                                          // 16: LF of Y                            (kLeafLfY)
+  return t;
+}
+
+int32_t HResultToStatus(int32_t hr) {   // OutputProcessor.cpp:134-151
+  if (hr >= 0) return EncoderStatus_Ok;
+  if ((uint32_t)hr == 0x80004004u) return EncoderStatus_UserCanceled;
+  if ((uint32_t)hr == 0x8007000Eu) return EncoderStatus_OutOfMemory;
+  return EncoderStatus_WriteError;
+}
+
+EncCodeDev UploadCode(Arena& A, const EncCode& c) {
+  EncCodeDev d;
+  d.ctx_map = A.Upload(c.ctx_map);
+  d.freq = A.Upload(c.freq);
+  d.start = A.Upload(c.start);
+  d.rmap = A.Upload(c.rmap);
+  d.num_clusters = c.num_clusters;
+  d.pad = 0;
+  return d;
+}
+
+void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const EncoderImageMetadata* md, IOCallbacks* io, ProgressProc progress) {
+  const uint32_t w = bmp->width, h = bmp->height;
+  if (!w || !h || !bmp->scan0 || bmp->stride < (uint64_t)w * 4) throw EncFail(EncoderStatus_EncodeError, "invalid bitmap");
+  if (md->iccProfile && md->iccProfileSize)
+    throw EncFail(EncoderStatus_EncodeError, "embedded ICC profiles are not supported on the MI355X encode path yet");
+  Arena A;
+  hipStream_t s = nullptr;
+  EncImage im;
+  memset(&im, 0, sizeof(im));
+  im.w = (int32_t)w; im.h = (int32_t)h;
+  im.w8 = (int32_t)((w + 7) / 8); im.h8 = (int32_t)((h + 7) / 8);
+  im.wp = im.w8 * 8; im.hp = im.h8 * 8;
+  im.xg = (int32_t)((w + 255) / 256); im.yg = (int32_t)((h + 255) / 256); im.ng = im.xg * im.yg;
+  im.xlf = (int32_t)((w + 2047) / 2048); im.ylf = (int32_t)((h + 2047) / 2048); im.nlf = im.xlf * im.ylf;
+  const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
+  // ---- 1. upload, pixel-format analysis (Encoder/JxlEncoder.cpp:33-77)
+  uint8_t* d_bgra = A.Get<uint8_t>((size_t)bmp->stride * h);
+  ENC_HIP(hipMemcpy(d_bgra, bmp->scan0, (size_t)bmp->stride * h, hipMemcpyHostToDevice));
+  im.bgra = d_bgra; im.stride = (int32_t)bmp->stride;
+  im.flags = A.Get<uint32_t>(4, true);
+  LaunchEncAnalyze(im, s);
+  uint32_t flags[2] = {0, 0};
+  ENC_HIP(hipMemcpy(flags, im.flags, sizeof(flags), hipMemcpyDeviceToHost));
+  im.gray = flags[0] ? 0 : 1;       // every pixel r == g == b and no ICC profile: one colour channel (:67-70)
+  im.has_alpha = flags[1] ? 1 : 0;  // some pixel a < 255 (:54-57)
+  Progress(progress, 5);
+  // ---- 2. quantiser and loop-filter parameters (only distance comes from the options, :319; effort is not used)
+  const float distance = std::max(0.05f, std::min(25.0f, opt->distance));
+  EncFrameInfo fi;
+  fi.encoding = 0;
+  fi.gab = true;
+  fi.epf_iters = 0;
+  for (float t : {0.7f, 1.5f, 4.0f}) if (distance >= t) fi.epf_iters++;
+  const double qf = 0.85 / distance;
+  const uint32_t global_scale = (uint32_t)std::max<long>(1, std::min<long>(8193 + 65535, std::lrint(65536.0 * qf / 16.0)));
+  const uint32_t quant_lf = (uint32_t)std::max<long>(1, std::min<long>(65536, std::lrint(1.1 / distance * 65536.0 / global_scale)));
+  const float inv_gs = 65536.0f / global_scale;
+  const float m_lf[3] = {1.0f / 4096, 1.0f / 512, 1.0f / 256};
+  for (int c = 0; c < 3; c++) im.inv_mul_lf[c] = 1.0f / (m_lf[c] * inv_gs / quant_lf);
+  im.mul_lf_y = m_lf[1] * inv_gs / quant_lf;
+  im.inv_gs = inv_gs;
+  im.x_dm = std::pow(0.8f, (float)fi.x_qm_scale - 2.0f);
+  im.b_dm = std::pow(0.8f, (float)fi.b_qm_scale - 2.0f);
+  im.qbias1 = 1.0f - 0.07005449891748593f;
+  im.qbias3 = 0.145f;
+  im.gab = fi.gab;
+  {
+    const float w1 = 0.115169525f, w2 = 0.061248592f, div = 1.0f + 4.0f * (w1 + w2);
+    for (int c = 0; c < 3; c++) { im.gab_w[c][0] = 1.0f / div; im.gab_w[c][1] = w1 / div; im.gab_w[c][2] = w2 / div; }
+  }
+  const StaticTables& st = GetStaticTables();
+  im.order8 = A.Upload(st.natural_order[0]);
+  im.dq8 = A.Upload(st.dq[0]);
+  im.basis8 = A.Upload(st.basis[0]);
+  // ---- 3. planes, front end
+  for (int c = 0; c < 3; c++) {
+    im.xyb[c] = A.Get<float>(npx);
+    im.pad[c] = A.Get<float>(npad);
+    im.lfq[c] = A.Get<int32_t>(ncell);
+    im.qs[c] = A.Get<int32_t>(ncell * 64);
+    im.nz[c] = A.Get<uint8_t>(ncell);
+    im.last[c] = A.Get<uint8_t>(ncell);
+  }
+  im.rawq = A.Get<int32_t>(ncell);
+  if (im.has_alpha) im.alpha_px = A.Get<int32_t>(npx);
+  Progress(progress, 15);
+  LaunchEncFrontEnd(im, s);
+  Progress(progress, 20);
+  // ---- 4. tokens + histograms
+  im.tok_lf = A.Get<DevToken>((size_t)im.nlf * kLfTokCap);
+  im.tok_meta = A.Get<DevToken>((size_t)im.nlf * kMetaTokCap);
+  im.tok_ac = A.Get<DevToken>((size_t)im.ng * kAcTokCap);
+  if (im.has_alpha) im.tok_alpha = A.Get<DevToken>((size_t)im.ng * kAlphaTokCap);
+  im.n_ac = A.Get<uint32_t>(im.ng, true);
+  im.hist_mod = A.Get<uint32_t>(kNumEncLeaves * kEncSyms, true);
+  im.hist_ac = A.Get<uint32_t>((size_t)kAcContexts * kEncSyms, true);
+  LaunchEncTokens(im, s);
+  std::vector<uint32_t> hist_mod(kNumEncLeaves * kEncSyms), hist_ac((size_t)kAcContexts * kEncSyms);
+  ENC_HIP(hipMemcpy(hist_mod.data(), im.hist_mod, hist_mod.size() * 4, hipMemcpyDeviceToHost));
+  ENC_HIP(hipMemcpy(hist_ac.data(), im.hist_ac, hist_ac.size() * 4, hipMemcpyDeviceToHost));
+  Progress(progress, 25);
+  // ---- 5. LfGlobal and HfGlobal (host): quantiser, MA tree, entropy codes
+  const bool single = im.ng == 1;
+  BitWriter lf_global, hf_global;
+  EncCode mcode, acode;
+  lf_global.Bool(true);   // default LF dequantisation factors
+  lf_global.U32(WB(11, 1), WB(11, 2049), WB(12, 4097), WB(16, 8193), global_scale);
+  lf_global.U32(WV(16), WB(5, 1), WB(8, 1), WB(16, 1), quant_lf);
+  lf_global.Bool(true);   // default block-context map
+  lf_global.Bool(true);   // default LF chroma-from-luma parameters
+  lf_global.Bool(true);   // global MA tree
+  WriteTree(MakeEncoderTree((uint32_t)im.nlf), lf_global);
+  {
+    std::vector<uint8_t> pinned(kNumEncLeaves, 0);
+    pinned[kLeafSharp] = pinned[kLeafCfl] = pinned[kLeafStrategy] = 1;   // constant channels: no token is ever written
+    BuildAndWriteCode(hist_mod.data(), kNumEncLeaves, 8, pinned, lf_global, mcode);
+  }
+  if (im.has_alpha) lf_global.Write(4, 3);   // global Modular image header: global tree, default predictor, no transforms
+  hf_global.Bool(true);                      // default dequantisation matrices
+  hf_global.Write(im.ng <= 1 ? 0 : 32 - __builtin_clz((unsigned)(im.ng - 1)), 0);   // one HF preset
+  hf_global.U32(WV(0x5F), WV(0x13), WV(0), WB(kNumOrders), 0);                       // natural coefficient orders
+  BuildAndWriteCode(hist_ac.data(), kAcContexts, 64, {}, hf_global, acode);
+  // ---- 6. ANS coding of every section on the GPU
+  im.mcode = UploadCode(A, mcode);
+  im.acode = UploadCode(A, acode);
+  const int nsec = im.nlf + im.ng + 1;   // + the global alpha stream of single-group frames
+  im.sec_cap = ((size_t)std::max(kLfTokCap + kMetaTokCap, kAcTokCap + kAlphaTokCap) * 6 + 256) & ~(size_t)15;
+  im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
+  im.sec_bits = A.Get<uint64_t>(nsec, true);
+  LaunchEncSections(im, s);
+  std::vector<uint64_t> sec_bits(nsec);
+  ENC_HIP(hipMemcpy(sec_bits.data(), im.sec_bits, sec_bits.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> off(nsec + 1, 0);
+  for (int i = 0; i < nsec; i++) off[i + 1] = off[i] + ((sec_bits[i] + 7) >> 3);
+  std::vector<uint8_t> packed(std::max<uint64_t>(off[nsec], 1));
+  {
+    uint64_t* d_off = A.Upload(off);
+    uint8_t* d_packed = A.Get<uint8_t>(packed.size());
+    LaunchEncCompact(im, d_off, d_packed, nsec, s);
+    ENC_HIP(hipMemcpy(packed.data(), d_packed, packed.size(), hipMemcpyDeviceToHost));
+  }
+  ENC_HIP(hipGetLastError());
+  Progress(progress, 30);
+  // ---- 7. codestream assembly
+  EncImageInfo ii;
+  ii.xsize = w; ii.ysize = h; ii.gray = im.gray; ii.alpha = im.has_alpha; ii.xyb = true;
+  BitWriter cs;
+  WriteCodestreamHeaders(ii, cs);
+  WriteFrameHeader(ii, fi, cs);
+  std::vector<std::vector<uint8_t>> sections;
+  if (single) {
+    // LfGlobal | LfGroup | HfGlobal | PassGroup share one bit stream
+    if (im.has_alpha) lf_global.AppendBits(packed.data() + off[im.nlf + im.ng], sec_bits[im.nlf + im.ng]);
+    const uint64_t hg_bits = hf_global.BitCount();
+    std::vector<uint8_t> hg = hf_global.Finish();
+    lf_global.AppendBits(packed.data() + off[0], sec_bits[0]);
+    lf_global.AppendBits(hg.data(), hg_bits);
+    lf_global.AppendBits(packed.data() + off[1], sec_bits[1]);
+    sections.push_back(lf_global.Finish());
+  } else {
+    sections.push_back(lf_global.Finish());
+    for (int g = 0; g < im.nlf; g++) sections.emplace_back(packed.begin() + off[g], packed.begin() + off[g + 1]);
+    sections.push_back(hf_global.Finish());
+    for (int g = 0; g < im.ng; g++) sections.emplace_back(packed.begin() + off[im.nlf + g], packed.begin() + off[im.nlf + g + 1]);
+  }
+  std::vector<uint32_t> sizes;
+  for (auto& sec : sections) sizes.push_back((uint32_t)sec.size());
+  WriteToc(sizes, cs);
+  std::vector<uint8_t> codestream = cs.Finish();
+  for (auto& sec : sections) codestream.insert(codestream.end(), sec.begin(), sec.end());
+  // ---- 8. container + output through the host callbacks (always boxes, Encoder/JxlEncoder.cpp:201)
+  std::vector<uint8_t> file = WriteContainer(codestream, md->exif, md->exifSize, md->xmp, md->xmpSize);
+  const size_t kChunk = 64 * 1024;   // OutputProcessor.cpp:16
+  size_t done = 0;
+  int last_pct = 30;
+  while (done < file.size()) {
+    const size_t n = std::min(kChunk, file.size() - done);
+    const int32_t st = HResultToStatus(io->Write(file.data() + done, n));
+    if (st != EncoderStatus_Ok) throw EncFail(st, st == EncoderStatus_WriteError ? "the output stream rejected a write" : "");
+    done += n;
+    const int pct = 30 + (int)(60.0 * done / file.size()) / 5 * 5;   // 30 -> 90 in steps of 5 (:340-344)
+    if (pct > last_pct) { Progress(progress, pct); last_pct = pct; }
+  }
+  Progress(progress, 95);
+}
+
+}  // namespace
+}  // namespace jxlhip
+
+using namespace jxlhip;
+
+extern "C" JXLFILETYPEIO_API EncoderStatus SaveImage(const BitmapData* bitmap, const EncoderOptions* options, const EncoderImageMetadata* metadata,
+                                   IOCallbacks* callbacks, ErrorInfo* err, ProgressProc progress) {
+  if (!bitmap || !options || !callbacks || !metadata) return EncoderStatus_NullParameter;   // Encoder/JxlEncoder.cpp:155-158
+  try {
+    Progress(progress, 0);   // :162
+    if (!callbacks->Write) throw EncFail(EncoderStatus_NullParameter, "");
+    if (options->lossless)
+      throw EncFail(EncoderStatus_EncodeError, "lossless (Modular) encoding is not built on the MI355X path yet; lossy VarDCT only");
+    EncodeLossy(bitmap, options, metadata, callbacks, progress);
+    return EncoderStatus_Ok;
+  } catch (const EncFail& e) {
+    if (e.status == EncoderStatus_EncodeError) SetEncErr(err, e.what());
+    return e.status;
+  } catch (const std::bad_alloc&) {
+    return EncoderStatus_OutOfMemory;
+  } catch (const std::exception& e) {
+    SetEncErr(err, e.what());
+    return EncoderStatus_EncodeError;
+  } catch (...) {
+    return EncoderStatus_EncodeError;   // never throw across the ABI (:382-389)
+  }
+}
+
+// ---------------------------------------------------------------------- host-only self tests of the writers (CPU tests, no GPU)
+namespace jxlhip {
+bool ReadBackTokens(const uint8_t* bytes, size_t nbytes, size_t num_ctx, const uint32_t* ctxs, const uint32_t* values, size_t n, std::string* why);
+bool ReadBackTree(const uint8_t* bytes, size_t nbytes, std::vector<DevTreeNode>* tree, std::string* why);
+}
+
+// Writes n pseudo-random tokens over num_ctx contexts with the encoder's code builder and reads them back with the decoder's
+// header parser and symbol reader.  Returns 0 on success (message in err otherwise).
+extern "C" JXLFILETYPEIO_API int32_t jxlhip_selftest_entropy(uint32_t seed, uint32_t num_ctx, uint32_t n, int32_t max_clusters,
+                                                             uint32_t pinned_ctx_plus1, ErrorInfo* err) {
+  try {
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+    auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (uint32_t)(s >> 32); };
+    std::vector<uint32_t> ctxs(n), vals(n), hist((size_t)num_ctx * kEncAlphabet, 0);
+    std::vector<uint8_t> pinned(num_ctx, 0);
+    if (pinned_ctx_plus1) pinned[pinned_ctx_plus1 - 1] = 1;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t c = rnd() % num_ctx;
+      // geometric-ish magnitudes whose spread depends on the context; a few large outliers exercise the extra bits
+      uint32_t v = 0;
+      const uint32_t spread = 1 + c % 7;
+      while ((rnd() % (spread + 1)) != 0 && v < 40) v++;
+      if (rnd() % 97 == 0) v = rnd() >> (rnd() % 30);
+      if (pinned[c]) v = 0;
+      ctxs[i] = c; vals[i] = v;
+      uint32_t tok, nb, bits;
+      HybridEncode(v, &tok, &nb, &bits);
+      hist[(size_t)c * kEncAlphabet + tok]++;
+    }
+    BitWriter bw;
+    EncCode code;
+    BuildAndWriteCode(hist.data(), num_ctx, max_clusters, pinned, bw, code);
+    std::vector<EncToken> toks;
+    for (uint32_t i = 0; i < n; i++)
+      if (!pinned[ctxs[i]]) toks.push_back(EncToken{ctxs[i], vals[i]});   // tokens of pinned contexts are never written
+    WriteTokensHost(toks, code, bw);
+    std::vector<uint8_t> bytes = bw.Finish();
+    std::string why;
+    // the decoder reads every token, the pinned ones included (they cost no bits and leave the state alone)
+    if (!ReadBackTokens(bytes.data(), bytes.size(), num_ctx, ctxs.data(), vals.data(), n, &why)) { SetEncErr(err, why.c_str()); return 1; }
+    return 0;
+  } catch (const std::exception& e) {
+    SetEncErr(err, e.what());
+    return 2;
+  }
+}
+
+// Serialises the encoder's MA tree and parses it back; returns 0 when node for node identical.
+extern "C" JXLFILETYPEIO_API int32_t jxlhip_selftest_tree(uint32_t nlf, ErrorInfo* err) {
+  try {
+    const std::vector<EncTreeNode> t = MakeEncoderTree(nlf);
+    BitWriter bw;
+    WriteTree(t, bw);
+    std::vector<uint8_t> bytes = bw.Finish();
+    std::vector<DevTreeNode> back;
+    std::string why;
+    if (!ReadBackTree(bytes.data(), bytes.size(), &back, &why)) { SetEncErr(err, why.c_str()); return 1; }
+    if (back.size() != t.size()) { SetEncErr(err, "node count"); return 2; }
+    uint32_t leaf = 0;
+    for (size_t i = 0; i < t.size(); i++) {
+      if (t[i].property >= 0) {
+        if (back[i].property != t[i].property || back[i].splitval != t[i].splitval) { SetEncErr(err, "inner node"); return 3; }
+      } else {
+        if (back[i].property >= 0 || (back[i].a & 0xFF) != (uint32_t)t[i].pred || (back[i].a >> 8) != leaf || back[i].splitval != t[i].offset ||
+            back[i].b != t[i].multiplier) { SetEncErr(err, "leaf"); return 4; }
+        leaf++;
+      }
+    }
+    return leaf == kNumEncLeaves ? 0 : 5;
+  } catch (const std::exception& e) {
+    SetEncErr(err, e.what());
+    return 6;
+  }
+}

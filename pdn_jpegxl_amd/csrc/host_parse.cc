@@ -1061,6 +1061,41 @@ void SplitContainer(const uint8_t* data, size_t size, ParsedFrame& f) {
 
 }  // namespace
 
+void BuildAliasTable(const std::vector<int>& counts, uint32_t log_alpha, uint64_t* out) { BuildAlias(counts, log_alpha, out); }
+
+// Test hooks for the encoder's host writers (CPU tests): read back what host_write.cc wrote with the decoder's own readers.
+bool ReadBackTokens(const uint8_t* bytes, size_t nbytes, size_t num_ctx, const uint32_t* ctxs, const uint32_t* values, size_t n,
+                    std::string* why) {
+  try {
+    Bits r(bytes, nbytes);
+    HostCode c;
+    ReadCode(r, num_ctx, c);
+    SymReader sr(c, r);
+    for (size_t i = 0; i < n; i++) {
+      const uint32_t v = sr.Get(ctxs[i]);
+      if (v != values[i]) { *why = "token " + std::to_string(i) + ": got " + std::to_string(v) + ", wrote " + std::to_string(values[i]); return false; }
+    }
+    if (!sr.Final()) { *why = "final ANS state"; return false; }
+    return true;
+  } catch (const std::exception& e) {
+    *why = e.what();
+    return false;
+  }
+}
+
+bool ReadBackTree(const uint8_t* bytes, size_t nbytes, std::vector<DevTreeNode>* tree, std::string* why) {
+  try {
+    Bits r(bytes, nbytes);
+    ParsedFrame f;
+    ReadTree(r, f, 1 << 16);
+    *tree = f.tree;
+    return true;
+  } catch (const std::exception& e) {
+    *why = e.what();
+    return false;
+  }
+}
+
 const uint8_t kCoveredX[kNumStrategies] = {1, 1, 1, 1, 2, 4, 1, 2, 1, 4, 2, 4, 1, 1, 1, 1, 1, 1, 8, 4, 8, 16, 8, 16, 32, 16, 32};
 const uint8_t kCoveredY[kNumStrategies] = {1, 1, 1, 1, 2, 4, 2, 1, 4, 1, 4, 2, 1, 1, 1, 1, 1, 1, 8, 8, 4, 16, 16, 8, 32, 32, 16};
 const uint8_t kStrategyOrderBucket[kNumStrategies] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};

@@ -43,10 +43,3 @@ def test_unsupported_streams_fail_loudly(oracle):
     with pytest.raises(api.FormatError) as e:
         api.load_image(oracle.encode(synth(300, 300, 4), lossless=True))
     assert e.value.status == "DecodeError" and "Modular" in str(e.value)
-
-
-def test_save_image_fails_loudly_until_built():
-    bgra = np.zeros((16, 16, 4), np.uint8)
-    with pytest.raises(api.JxlError) as e:
-        api.save_image(bgra)
-    assert e.value.status == "EncodeError"

@@ -1,0 +1,133 @@
+"""GPU tests of the encode path: SaveImage driven like src/Interop/JpegXLNative.cs drives it (BGRA surface in, Write/Seek/progress
+callbacks out), checked with the CPU oracle's decoder and against the oracle's own encoder on the same pixels."""
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bgra_of(rgba):
+    return np.ascontiguousarray(rgba[..., [2, 1, 0, 3]])
+
+
+def psnr(a, b):
+    mse = np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+@pytest.mark.parametrize("size,seed", [((300, 280), 3), ((520, 400), 4), ((264, 2100), 5)])
+def test_save_image_round_trip_rgba(oracle, size, seed):
+    w, h = size
+    img = synth(w, h, seed)                       # RGBA with a soft alpha mask: the Rgba path (Encoder/JxlEncoder.cpp:33-77)
+    data = api.save_image(bgra_of(img), distance=1.0)
+    assert data[:12] == bytes([0, 0, 0, 0xC]) + b"JXL \r\n\x87\n"   # always the container (:201)
+    od = oracle.decode(data)
+    assert od.pixels.shape == (h, w, 4)
+    assert (od.pixels[..., 3] == img[..., 3]).all()                  # alpha is lossless
+    ours = psnr(od.pixels[..., :3], img[..., :3])
+    ref = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=1)).pixels   # the oracle's encoder, 8x8 DCT only
+    theirs = psnr(ref[..., :3], img[..., :3])
+    assert ours > 34.0 and ours > theirs - 0.5, (ours, theirs)
+    # the product decoder reads its own files back to what the oracle decodes from them
+    got = api.load_image(data)
+    d = np.abs(got.pixels.astype(int) - od.pixels.astype(int))
+    assert got.pixels.shape == od.pixels.shape and d.max() <= 1
+
+
+def test_quantised_data_matches_the_oracle_encoder(oracle):
+    """Same pixels through both encoders (8x8 DCT only): quantised LF, quant field and HF coefficients agree except where a
+    float32 rounding difference (cbrt / pow / summation order) flips a value sitting on a quantisation boundary."""
+    img = synth(512, 384, 7)
+    a = oracle.decode(api.save_image(bgra_of(img), distance=1.0), want_dump=True)
+    b = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=1), want_dump=True)
+    assert (a.planes["strategy"] == b.planes["strategy"]).all()
+    rq = a.planes["raw_quant"] != b.planes["raw_quant"]
+    assert rq.mean() < 0.01
+    for c in range(3):
+        d = np.abs(a.planes["lf_quant"][c].astype(int) - b.planes["lf_quant"][c].astype(int))
+        assert d.max() <= 1 and (d > 0).mean() < 0.01
+    # HF: compare only cells whose quant field agrees
+    w8 = a.w8
+    cells_ok = ~rq.reshape(-1)
+    for c in range(3):
+        qa = a.planes["qcoef"][c].reshape(a.h8, 8, w8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+        qb = b.planes["qcoef"][c].reshape(b.h8, 8, w8, 8).transpose(0, 2, 1, 3).reshape(-1, 64)
+        d = np.abs(qa[cells_ok].astype(int) - qb[cells_ok].astype(int))
+        # B is coded after subtracting the dequantised Y (chroma from luma), so it also moves wherever Y flipped
+        assert d.max() <= 1 and (d > 0).mean() < (0.015 if c == 2 else 0.004), (c, d.max(), (d > 0).mean())
+
+
+def test_pixel_format_analysis(oracle):
+    img = synth(300, 200, 9)
+    opaque = img.copy()
+    opaque[..., 3] = 255
+    od = oracle.decode(api.save_image(bgra_of(opaque)))
+    assert od.pixels.shape == (200, 300, 3)                      # opaque input: no alpha channel is written (:54-57)
+    gray = opaque.copy()
+    gray[..., 0] = gray[..., 1] = gray[..., 2] = img[..., 1]
+    od = oracle.decode(api.save_image(bgra_of(gray)))
+    assert od.pixels.shape == (200, 300, 1)                      # r == g == b everywhere: one colour channel (:67-70)
+    assert psnr(od.pixels[..., 0], gray[..., 0]) > 34.0
+    gray[..., 3] = img[..., 3]
+    od = oracle.decode(api.save_image(bgra_of(gray)))
+    assert od.pixels.shape == (200, 300, 2) and (od.pixels[..., 1] == img[..., 3]).all()
+
+
+def test_metadata_boxes_and_strided_surface(oracle):
+    img = synth(200, 120, 11)
+    exif = b"\0\0\0\0II*\0" + bytes(range(40))
+    xmp = b"<x:xmpmeta xmlns:x='adobe:ns:meta/'/>"
+    surface = np.zeros((120, 256, 4), np.uint8)                  # stride > width * 4
+    surface[:, :200] = bgra_of(img)
+    data = api.save_image(surface[:, :200], exif=exif, xmp=xmp)
+    od = oracle.decode(data)
+    assert od.exif == exif and od.xml == xmp
+    assert od.pixels.shape == (120, 200, 4) and psnr(od.pixels[..., :3], img[..., :3]) > 34.0
+    got = api.load_image(data)
+    assert got.exif == exif and got.xmp == xmp
+
+
+def test_progress_cancellation_and_write_errors():
+    bgra = bgra_of(synth(300, 300, 13))
+    seen = []
+    api.save_image(bgra, progress=lambda p: seen.append(p) or True)
+    assert seen[0] == 0 and seen[-1] == 95 and seen == sorted(seen) and {5, 15, 20, 25, 30, 90} <= set(seen)
+    for stop_at in (0, 20, 60):
+        with pytest.raises(api.JxlError) as e:
+            api.save_image(bgra, progress=lambda p: p < stop_at)
+        assert e.value.status == "UserCanceled"
+    for hr, status in ((0x80004004, "UserCanceled"), (0x8007000E, "OutOfMemory"), (0x80070005, "WriteError")):
+        with pytest.raises(api.JxlError) as e:
+            api.save_image(bgra, write_result=hr)
+        assert e.value.status == status
+
+
+def test_distance_controls_rate_and_quality(oracle):
+    img = synth(400, 300, 17)
+    sizes, quality = [], []
+    for d in (0.5, 1.0, 2.0, 4.0):
+        data = api.save_image(bgra_of(img), distance=d)
+        sizes.append(len(data))
+        quality.append(psnr(oracle.decode(data).pixels[..., :3], img[..., :3]))
+    assert sizes == sorted(sizes, reverse=True) and quality == sorted(quality, reverse=True)
+
+
+def test_unbuilt_options_fail_loudly():
+    bgra = bgra_of(synth(64, 64, 1))
+    with pytest.raises(api.JxlError) as e:
+        api.save_image(bgra, icc=b"not a real profile")
+    assert e.value.status == "EncodeError" and "ICC" in str(e.value)
+
+
+def test_4k_encode_decodes_on_both_sides(oracle):
+    """BASELINE.json configs[3]: 3840x2160 lossy encode at distance 1.0."""
+    img = synth(3840, 2160, 2)
+    data = api.save_image(bgra_of(img), distance=1.0)
+    got = api.load_image(data)
+    assert got.pixels.shape == (2160, 3840, 4) and (got.pixels[..., 3] == img[..., 3]).all()
+    assert psnr(got.pixels[..., :3], img[..., :3]) > 34.0
+    od = oracle.decode(data)
+    assert np.abs(got.pixels.astype(int) - od.pixels.astype(int)).max() <= 1

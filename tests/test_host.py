@@ -122,3 +122,32 @@ def test_golden_files_parse(oracle):
     for name in ("rgba_300x280_mix_d2", "rgb_333x257_d1", "gray_270x300_d3"):
         st, facts, msg = api.parse_check(open(os.path.join(GOLD, name + ".jxl"), "rb").read())
         assert st == "Ok", (name, msg)
+
+
+# ---------------------------------------------------------------- encoder-side host writers (no GPU)
+def _selftests():
+    import ctypes as C
+    L = api.lib()
+    L.jxlhip_selftest_entropy.restype = C.c_int32
+    L.jxlhip_selftest_entropy.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(api.ErrorInfo)]
+    L.jxlhip_selftest_tree.restype = C.c_int32
+    L.jxlhip_selftest_tree.argtypes = [C.c_uint32, C.POINTER(api.ErrorInfo)]
+    return L
+
+
+@pytest.mark.parametrize("seed,num_ctx,n,max_clusters,pinned", [
+    (1, 1, 1000, 1, 0), (2, 9, 20000, 8, 4), (3, 9, 5000, 8, 0), (4, 300, 100000, 16, 0), (5, 7425, 300000, 64, 0),
+    (6, 2, 10, 8, 0), (7, 40, 3, 8, 0), (8, 1, 0, 1, 0), (9, 600, 100000, 255, 0)])
+def test_entropy_code_written_by_the_encoder_reads_back(seed, num_ctx, n, max_clusters, pinned):
+    """BuildAndWriteCode + WriteTokensHost (host_write.cc) -> ReadCode + SymReader (host_parse.cc): every token value and the
+    final ANS state.  Covers the simple and the entropy-coded context map, 1..255 clusters, empty and pinned contexts."""
+    import ctypes as C
+    err = api.ErrorInfo()
+    assert _selftests().jxlhip_selftest_entropy(seed, num_ctx, n, max_clusters, pinned, C.byref(err)) == 0, err.errorMessage
+
+
+@pytest.mark.parametrize("nlf", [1, 4, 64])
+def test_encoder_tree_reads_back(nlf):
+    import ctypes as C
+    err = api.ErrorInfo()
+    assert _selftests().jxlhip_selftest_tree(nlf, C.byref(err)) == 0, err.errorMessage

@@ -75,6 +75,7 @@ struct JxoEncodeParams {
   int32_t adaptive_lf_smoothing;
   int32_t lossless_predictor;
   int32_t lossless_squeeze;
+  int32_t lossless_tree;
   int32_t num_threads;
 };
 
@@ -86,7 +87,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.strategy_mode = ep->strategy_mode; p.fixed_strategy = ep->fixed_strategy; p.seed = ep->seed;
     p.epf_iters = ep->epf_iters; p.gaborish = ep->gaborish != 0; p.container = ep->container != 0;
     p.adaptive_lf_smoothing = ep->adaptive_lf_smoothing != 0;
-    p.lossless_predictor = ep->lossless_predictor; p.lossless_squeeze = ep->lossless_squeeze != 0;
+    p.lossless_predictor = ep->lossless_predictor; p.lossless_squeeze = ep->lossless_squeeze != 0; p.lossless_tree = ep->lossless_tree;
     p.num_threads = ep->num_threads;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);

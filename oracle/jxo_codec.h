@@ -56,6 +56,7 @@ struct EncodeParams {
   bool adaptive_lf_smoothing = true;
   int lossless_predictor = 6;   // leaf predictor for lossless modular (6 = weighted)
   bool lossless_squeeze = false;
+  int lossless_tree = 0;        // 0: contexts from the weighted predictor's error (property 15); 1: local-gradient contexts (W-NW, NW-N)
   int num_threads = 1;
 };
 

@@ -65,8 +65,20 @@ Tree MakeVarDctTree(uint32_t nlf) {
   return MakeBfsTree(b.t, root);
 }
 
-Tree MakeLosslessTree(int predictor) {
+Tree MakeLosslessTree(int predictor, int mode) {
   TreeBuilder b;
+  if (mode == 1) {
+    // no weighted predictor anywhere: horizontal gradient W-NW (property 10) split three ways, then the vertical one NW-N (11)
+    auto vert = [&]() {
+      int hi = b.Leaf(predictor), mid = b.Leaf(predictor), lo = b.Leaf(predictor);
+      int inner = b.Split(11, -4, mid, lo);
+      return b.Split(11, 3, hi, inner);
+    };
+    int hi = vert(), mid = vert(), lo = vert();
+    int inner = b.Split(10, -6, mid, lo);
+    int root = b.Split(10, 5, hi, inner);
+    return MakeBfsTree(b.t, root);
+  }
   // contexts from the weighted predictor's max error (property 15), symmetric buckets
   static const int32_t cuts[] = {-80, -24, -8, -3, -1, 0, 2, 7, 23, 79};
   const int ncut = sizeof(cuts) / sizeof(cuts[0]);
@@ -483,7 +495,7 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
     ForwardSqueeze(full, sp);
   }
   gh_global.transforms = full.transforms;
-  Tree tree = MakeLosslessTree(p.lossless_predictor);
+  Tree tree = MakeLosslessTree(p.lossless_predictor, p.lossless_tree);
   WPHeader wph;
   const uint32_t nlf = f.num_lf_groups, ng = f.num_groups;
   const int gd = f.group_dim;

@@ -318,10 +318,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
+    size_t mod_plane[4], mod_desc;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
-  int total_lf = 0, total_groups = 0;
+  int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
     const ParsedFrame& f = frames[i];
@@ -333,6 +334,17 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.m_cmap = blob.Take(f.mcode.ctx_map.size());
     l.m_cfg = blob.Take(4 * f.mcode.cfg.size());
     l.m_alias = blob.Take(8 * f.mcode.alias.size());
+    if (f.encoding == 1) {
+      // Modular (lossless) frame: whole-image int32 channel planes, no VarDCT workspace
+      const bool resident_m = dev_data && dev_data[i] && f.cs_contiguous;
+      l.cs = resident_m ? 0 : blob.Take(f.cs_size + 16);
+      l.z_status = ws_zero.Take(64);
+      const int nch = f.ncolor + (f.alpha_index >= 0 ? 1 : 0);
+      for (int c = 0; c < nch; c++) l.mod_plane[c] = ws.Take(4 * (size_t)f.xsize * f.ysize);
+      l.mod_desc = ws.Take((size_t)f.ng * 4 * sizeof(ChanDesc));
+      n_mod_tasks += ((int)f.ng + 63) / 64;
+      continue;
+    }
     l.a_cmap = blob.Take(f.acode.ctx_map.size());
     l.a_cfg = blob.Take(4 * f.acode.cfg.size());
     l.a_alias = blob.Take(8 * f.acode.alias.size());
@@ -370,7 +382,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   else {
     size_t lds_est = 0;
     for (int i = 0; i < n; i++)
-      if (parse_status[i] == DecoderStatus_Ok)
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0)
         lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 2 + 8448 * 2 + 64 + 4 * (96 + 64 + 128));
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
@@ -379,7 +391,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   const int per_wg = 256 / lane_stride;
   int n_pass_wg = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
   // Lane mapping of the alpha phase-A kernel (one wavefront per workgroup, sections of one image per wavefront): spread the
@@ -389,17 +401,18 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   else {
     int alpha_sections = 0;
     for (int i = 0; i < n; i++)
-      if (parse_status[i] == DecoderStatus_Ok && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
     while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
   }
   const int per_alpha_wg = 64 / alpha_stride;
   int n_alpha_wg = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
   int n_lf_ans = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok) n_lf_ans += ((int)frames[i].nlf + 63) / 64;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_lf_ans += ((int)frames[i].nlf + 63) / 64;
   const size_t off_lf_ans_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_lf_ans));
+  const size_t off_mod_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_mod_tasks));
   const size_t off_alpha_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_alpha_wg));
   const size_t zero_bytes = Align(ws_zero.off, 256);
   EnsureBlob(blob.off);
@@ -424,7 +437,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   SectionTask* pass_tasks = (SectionTask*)(h_blob + off_pass_tasks);
   SectionTask* alpha_tasks = (SectionTask*)(h_blob + off_alpha_tasks);
   SectionTask* lf_ans_tasks = (SectionTask*)(h_blob + off_lf_ans_tasks);
-  int nlf_t = 0, npass_t = 0, nalpha_t = 0, nlf_ans_t = 0, max_groups = 1;
+  SectionTask* mod_tasks = (SectionTask*)(h_blob + off_mod_tasks);
+  int nlf_t = 0, npass_t = 0, nalpha_t = 0, nlf_ans_t = 0, nmod_t = 0, max_groups = 1, max_mod_groups = 1;
+  size_t lds_mod = 0, max_mod_pixels = 1;
   uint8_t* wz = d_ws;
   uint8_t* wr = d_ws + zero_bytes;
   for (int i = 0; i < n; i++) {
@@ -462,7 +477,6 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       dc.log_alpha = hc.log_alpha;
     };
     code(f.mcode, l.m_cmap, l.m_cfg, l.m_alias, d.mcode);
-    code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
     d.sec_off = (const uint64_t*)(d_blob + l.sec_off);
     d.sec_size = (const uint32_t*)(d_blob + l.sec_size);
     d.tree = (const DevTreeNode*)(d_blob + l.tree);
@@ -471,6 +485,28 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (resident) d.cs = dev_data[i] + f.cs_file_offset;
     else { put(l.cs, f.cs, f.cs_size); d.cs = d_blob + l.cs; }
     d.cs_size = f.cs_size;
+    if (f.encoding == 1) {
+      d.is_modular = 1;
+      d.w8 = d.h8 = d.wt = d.ht = d.wp = d.hp = 0;   // nothing of the VarDCT pipeline runs for this image
+      d.mod_nch = d.nch_out;
+      d.group_dim = (int32_t)f.group_dim;
+      d.single = f.single ? 1 : 0;
+      d.mod_data_bits = f.mod_data_bits;
+      d.mod_ntr = (int32_t)std::min<size_t>(4, f.mod_transforms.size());
+      for (int t = 0; t < d.mod_ntr; t++) { d.mod_tr[t][0] = (int32_t)f.mod_transforms[t].begin_c; d.mod_tr[t][1] = (int32_t)f.mod_transforms[t].rct_type; }
+      for (int c = 0; c < d.mod_nch; c++) d.mod_plane[c] = (int32_t*)(wr + l.mod_plane[c]);
+      d.mod_desc = (ChanDesc*)(wr + l.mod_desc);
+      d.status = (uint32_t*)(wz + l.z_status);
+      status_off[i] = l.z_status;
+      d.out = dev_out[i];
+      auto code_lds_m = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
+      lds_mod = std::max(lds_mod, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
+      max_mod_groups = std::max<int>(max_mod_groups, (int)f.ng);
+      max_mod_pixels = std::max(max_mod_pixels, (size_t)f.xsize * f.ysize);
+      for (uint32_t g = 0; g < f.ng; g += 64) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, f.ng - g), 0};
+      continue;
+    }
+    code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
     d.num_presets = f.num_presets;
     d.num_block_ctx = f.num_block_ctx;
     memcpy(d.block_ctx_map, f.block_ctx_map.data(), std::min(sizeof(d.block_ctx_map), f.block_ctx_map.size()));
@@ -604,6 +640,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
   LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, stream);
   Mark("filters+output", stream, 2);
+  if (nmod_t) {
+    // Modular (lossless) frames of the batch; they depend on nothing but the upload
+    if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
+    LaunchModular(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
+                  max_mod_pixels, stream);
+    Mark("modular", stream, 2);
+  }
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok)
       HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, stream));

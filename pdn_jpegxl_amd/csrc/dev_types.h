@@ -117,6 +117,13 @@ struct DevImage {
   uint64_t lf_start_bits;   // where the GPU starts (global alpha channel, then the LF group)
   uint64_t hf_start_bits;   // after HfGlobal (filled in once the host has parsed it)
   uint64_t* lf_end_bits;    // written by lf_group_kernel: bit position after the LF group
+  // Modular frames (lossless): up to 4 channels of the whole image, decoded per group (or, for a frame that fits one
+  // group, from the GlobalModular stream), then inverse colour transforms and interleaving in modular_out_kernel
+  int32_t is_modular, mod_nch, group_dim, mod_ntr;
+  int32_t mod_tr[4][2];     // reversible colour transforms in stream order: begin channel, type
+  int32_t* mod_plane[4];    // w*h each
+  ChanDesc* mod_desc;       // per group: 4 entries
+  uint64_t mod_data_bits;   // single-group frames: bit position of the channel data inside LfGlobal
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
   int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
   float* tmp[3];            // wp*hp

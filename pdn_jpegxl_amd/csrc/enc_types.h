@@ -18,6 +18,7 @@ constexpr uint32_t kLfTokCap = 3 * 65536;     // tokens per LF group: LF coeffic
 constexpr uint32_t kMetaTokCap = 65536;       // ... and quant-field row of the block info
 constexpr uint32_t kAcTokCap = 3 * 65 * 1024; // tokens per group: 1 + 64 per (block, channel)
 constexpr uint32_t kAlphaTokCap = 65536;
+constexpr uint32_t kLlTokCap = 4 * 65536;     // lossless: up to four channels per group
 
 struct EncCodeDev {
   const uint8_t* ctx_map;
@@ -62,6 +63,10 @@ struct EncImage {
   uint32_t* n_ac;           // [ng]
   uint32_t* hist_mod;       // [kNumEncLeaves][kEncSyms]
   uint32_t* hist_ac;        // [kAcContexts][kEncSyms]
+  // lossless (Modular) frames: whole-image integer channels, tokens per group
+  int32_t* ll_plane[4];
+  int32_t ll_nch, ll_rct;   // ll_rct: RGB is coded as YCoCg-R (reversible colour transform 6)
+  DevToken* tok_ll;         // [ng][4 * 65536]
   // entropy coding
   EncCodeDev mcode, acode;
   uint8_t* sec_bytes;       // section s at s * sec_cap

@@ -455,6 +455,73 @@ __global__ void enc_compact_kernel(EncImage im, const uint64_t* dst_off, uint8_t
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes; i += (uint64_t)gridDim.x * blockDim.x) dst[dst_off[s] + i] = src[i];
 }
 
+// ------------------------------------------------------------------ lossless (Modular) frames
+// BGRA8 -> integer channel planes: Gray(A) takes the B channel (PixelFormatConversion.cpp:34,60); RGB goes through the
+// reversible YCoCg-R transform (RCT type 6), alpha is the last channel.
+__global__ void enc_ll_planes_kernel(EncImage im) {
+  const size_t n = (size_t)im.w * im.h;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % im.w), y = (int)(i / im.w);
+    const uchar4 p = *(const uchar4*)(im.bgra + (size_t)y * im.stride + (size_t)x * 4);   // B, G, R, A
+    int c = 0;
+    if (im.gray) im.ll_plane[c++][i] = p.x;
+    else {
+      const int32_t R = p.z, G = p.y, B = p.x;
+      const int32_t co = R - B, tmp = B + (co >> 1), cg = G - tmp, yy = tmp + (cg >> 1);
+      im.ll_plane[0][i] = yy; im.ll_plane[1][i] = co; im.ll_plane[2][i] = cg;
+      c = 3;
+    }
+    if (im.has_alpha) im.ll_plane[c][i] = p.w;
+  }
+}
+
+// gradient-predicted residuals of every channel of one group; context = channel (leaf id 3 - channel)
+__global__ __launch_bounds__(256) void enc_ll_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_h[4 * kEncSyms];
+  for (int i = threadIdx.x; i < 4 * (int)kEncSyms; i += 256) s_h[i] = 0;
+  __syncthreads();
+  const int g = blockIdx.y;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
+  const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
+  const int per = gw * gh, n = per * im.ll_nch;
+  DevToken* out = im.tok_ll + (size_t)g * kLlTokCap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const int c = i / per, r = i % per, y = r / gw, x = r % gw;
+    const int32_t* pl = im.ll_plane[c] + (size_t)y0 * im.w + x0;
+    const int32_t v = pl[(size_t)y * im.w + x];
+    int32_t W, N, NW;
+    if (x == 0) { W = y ? pl[(size_t)(y - 1) * im.w] : 0; N = W; NW = W; }
+    else {
+      W = pl[(size_t)y * im.w + x - 1];
+      N = y ? pl[(size_t)(y - 1) * im.w + x] : W;
+      NW = y ? pl[(size_t)(y - 1) * im.w + x - 1] : W;
+    }
+    DevToken t;
+    t.ctx = 3 - c;
+    t.value = PackSignedD(v - GradientPred(W, N, NW));
+    out[i] = t;
+    uint32_t tok, nb, bits;
+    HybridD(t.value, &tok, &nb, &bits);
+    atomicAdd(&s_h[t.ctx * kEncSyms + tok], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 4 * (int)kEncSyms; i += 256)
+    if (s_h[i]) atomicAdd(&im.hist_mod[i], s_h[i]);
+}
+
+__global__ __launch_bounds__(64) void enc_ll_sections_kernel(EncImage im) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= im.ng) return;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
+  LaneWriter w;
+  w.Init(im.sec_bytes + (size_t)g * im.sec_cap);
+  if (im.ng > 1) w.Put(4, 3);   // group header; a single-group frame continues the GlobalModular stream of LfGlobal
+  EncodeStream(im.tok_ll + (size_t)g * kLlTokCap, (uint32_t)(gw * gh * im.ll_nch), im.mcode, w);
+  im.sec_bits[g] = w.Finish();
+}
+
 // ------------------------------------------------------------------ launch wrappers
 static inline unsigned GridFor(size_t work, unsigned cap = 8192) {
   size_t b = (work + 255) / 256;
@@ -478,6 +545,14 @@ void LaunchEncTokens(const EncImage& im, hipStream_t s) {
 void LaunchEncSections(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + 63) / 64)), dim3(64), 0, s, im);
   if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
+}
+void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s) {
+  if (stage == 0) {
+    hipLaunchKernelGGL(enc_ll_planes_kernel, dim3(GridFor((size_t)im.w * im.h)), dim3(256), 0, s, im);
+    hipLaunchKernelGGL(enc_ll_tokens_kernel, dim3(64, im.ng), dim3(256), 0, s, im);
+  } else {
+    hipLaunchKernelGGL(enc_ll_sections_kernel, dim3((unsigned)((im.ng + 63) / 64)), dim3(64), 0, s, im);
+  }
 }
 void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s) {
   hipLaunchKernelGGL(enc_compact_kernel, dim3(64, nsec), dim3(256), 0, s, im, dst_off, dst, nsec);

@@ -27,6 +27,7 @@ void LaunchEncFrontEnd(const EncImage& im, hipStream_t s);
 void LaunchEncTokens(const EncImage& im, hipStream_t s);
 void LaunchEncSections(const EncImage& im, hipStream_t s);
 void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s);
+void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s);
 
 namespace {
 
@@ -116,32 +117,140 @@ EncCodeDev UploadCode(Arena& A, const EncCode& c) {
   return d;
 }
 
-void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const EncoderImageMetadata* md, IOCallbacks* io, ProgressProc progress) {
+// Container + output through the host callbacks (always boxes, Encoder/JxlEncoder.cpp:201) in chunks of at most 64 KiB.
+void EmitFile(const std::vector<uint8_t>& codestream, const EncoderImageMetadata* md, IOCallbacks* io, ProgressProc progress) {
+  std::vector<uint8_t> file = WriteContainer(codestream, md->exif, md->exifSize, md->xmp, md->xmpSize);
+  const size_t kChunk = 64 * 1024;   // OutputProcessor.cpp:16
+  size_t done = 0;
+  int last_pct = 30;
+  while (done < file.size()) {
+    const size_t n = std::min(kChunk, file.size() - done);
+    const int32_t st = HResultToStatus(io->Write(file.data() + done, n));
+    if (st != EncoderStatus_Ok) throw EncFail(st, st == EncoderStatus_WriteError ? "the output stream rejected a write" : "");
+    done += n;
+    const int pct = 30 + (int)(60.0 * done / file.size()) / 5 * 5;   // 30 -> 90 in steps of 5 (:340-344)
+    if (pct > last_pct) { Progress(progress, pct); last_pct = pct; }
+  }
+  Progress(progress, 95);
+}
+
+// Geometry + upload + pixel-format analysis shared by the lossy and the lossless path (Encoder/JxlEncoder.cpp:33-77).
+void BeginImage(const BitmapData* bmp, const EncoderImageMetadata* md, Arena& A, EncImage& im, ProgressProc progress) {
   const uint32_t w = bmp->width, h = bmp->height;
   if (!w || !h || !bmp->scan0 || bmp->stride < (uint64_t)w * 4) throw EncFail(EncoderStatus_EncodeError, "invalid bitmap");
   if (md->iccProfile && md->iccProfileSize)
     throw EncFail(EncoderStatus_EncodeError, "embedded ICC profiles are not supported on the MI355X encode path yet");
-  Arena A;
-  hipStream_t s = nullptr;
-  EncImage im;
   memset(&im, 0, sizeof(im));
   im.w = (int32_t)w; im.h = (int32_t)h;
   im.w8 = (int32_t)((w + 7) / 8); im.h8 = (int32_t)((h + 7) / 8);
   im.wp = im.w8 * 8; im.hp = im.h8 * 8;
   im.xg = (int32_t)((w + 255) / 256); im.yg = (int32_t)((h + 255) / 256); im.ng = im.xg * im.yg;
   im.xlf = (int32_t)((w + 2047) / 2048); im.ylf = (int32_t)((h + 2047) / 2048); im.nlf = im.xlf * im.ylf;
-  const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
-  // ---- 1. upload, pixel-format analysis (Encoder/JxlEncoder.cpp:33-77)
   uint8_t* d_bgra = A.Get<uint8_t>((size_t)bmp->stride * h);
   ENC_HIP(hipMemcpy(d_bgra, bmp->scan0, (size_t)bmp->stride * h, hipMemcpyHostToDevice));
   im.bgra = d_bgra; im.stride = (int32_t)bmp->stride;
   im.flags = A.Get<uint32_t>(4, true);
-  LaunchEncAnalyze(im, s);
+  LaunchEncAnalyze(im, nullptr);
   uint32_t flags[2] = {0, 0};
   ENC_HIP(hipMemcpy(flags, im.flags, sizeof(flags), hipMemcpyDeviceToHost));
   im.gray = flags[0] ? 0 : 1;       // every pixel r == g == b and no ICC profile: one colour channel (:67-70)
   im.has_alpha = flags[1] ? 1 : 0;  // some pixel a < 255 (:54-57)
   Progress(progress, 5);
+}
+
+// Lossless: a Modular frame in the original (sRGB) colour space (Encoder/JxlEncoder.cpp:214,325); 256x256 groups, YCoCg-R for RGB,
+// gradient predictor, one context per channel.
+void EncodeLossless(const BitmapData* bmp, const EncoderImageMetadata* md, IOCallbacks* io, ProgressProc progress) {
+  Arena A;
+  hipStream_t s = nullptr;
+  EncImage im;
+  BeginImage(bmp, md, A, im, progress);
+  const size_t npx = (size_t)im.w * im.h;
+  im.lossless = 1;
+  im.ll_nch = (im.gray ? 1 : 3) + im.has_alpha;
+  im.ll_rct = im.gray ? 0 : 1;
+  for (int c = 0; c < im.ll_nch; c++) im.ll_plane[c] = A.Get<int32_t>(npx);
+  im.tok_ll = A.Get<DevToken>((size_t)im.ng * kLlTokCap);
+  im.hist_mod = A.Get<uint32_t>(kNumEncLeaves * kEncSyms, true);
+  Progress(progress, 15);
+  LaunchEncLossless(im, 0, s);
+  std::vector<uint32_t> hist(4 * kEncSyms);
+  ENC_HIP(hipMemcpy(hist.data(), im.hist_mod, hist.size() * 4, hipMemcpyDeviceToHost));
+  Progress(progress, 25);
+  // LfGlobal: tree on the channel index (leaf ids: channel 3, 2, 1, 0), code, GlobalModular header
+  const bool single = im.ng == 1;
+  BitWriter lf_global;
+  EncCode mcode;
+  lf_global.Bool(true);   // default LF dequantisation factors (read for every frame encoding)
+  lf_global.Bool(true);   // global MA tree
+  {
+    std::vector<EncTreeNode> t;
+    t.push_back(EncTreeNode{0, 1, 0, 0, 1});     // 0: channel > 1 ? 1 : 2
+    t.push_back(EncTreeNode{0, 2, 0, 0, 1});     // 1: channel > 2 ? 3 : 4
+    t.push_back(EncTreeNode{0, 0, 0, 0, 1});     // 2: channel > 0 ? 5 : 6
+    for (int i = 0; i < 4; i++) t.push_back(EncTreeNode{-1, 0, 5, 0, 1});   // gradient predictor leaves: channel 3, 2, 1, 0
+    WriteTree(t, lf_global);
+  }
+  BuildAndWriteCode(hist.data(), 4, 4, {}, lf_global, mcode);
+  lf_global.Bool(true);   // use the global tree
+  lf_global.Bool(true);   // default weighted-predictor parameters
+  lf_global.U32(WV(0), WV(1), WB(4, 2), WB(8, 18), im.ll_rct ? 1 : 0);
+  if (im.ll_rct) {
+    lf_global.Write(2, 0);                                            // transform id 0: reversible colour transform
+    lf_global.U32(WB(3), WB(6, 8), WB(10, 72), WB(13, 1096), 0);      // first channel
+    lf_global.U32(WV(6), WB(2), WB(4, 2), WB(6, 10), 6);              // type 6: YCoCg-R
+  }
+  im.mcode = UploadCode(A, mcode);
+  const int nsec = im.ng;
+  im.sec_cap = ((size_t)kLlTokCap * 6 + 256) & ~(size_t)15;
+  im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
+  im.sec_bits = A.Get<uint64_t>(nsec, true);
+  LaunchEncLossless(im, 1, s);
+  std::vector<uint64_t> sec_bits(nsec);
+  ENC_HIP(hipMemcpy(sec_bits.data(), im.sec_bits, sec_bits.size() * 8, hipMemcpyDeviceToHost));
+  std::vector<uint64_t> off(nsec + 1, 0);
+  for (int i = 0; i < nsec; i++) off[i + 1] = off[i] + ((sec_bits[i] + 7) >> 3);
+  std::vector<uint8_t> packed(std::max<uint64_t>(off[nsec], 1));
+  {
+    uint64_t* d_off = A.Upload(off);
+    uint8_t* d_packed = A.Get<uint8_t>(packed.size());
+    LaunchEncCompact(im, d_off, d_packed, nsec, s);
+    ENC_HIP(hipMemcpy(packed.data(), d_packed, packed.size(), hipMemcpyDeviceToHost));
+  }
+  ENC_HIP(hipGetLastError());
+  Progress(progress, 30);
+  EncImageInfo ii;
+  ii.xsize = (uint32_t)im.w; ii.ysize = (uint32_t)im.h; ii.gray = im.gray; ii.alpha = im.has_alpha; ii.xyb = false;
+  EncFrameInfo fi;
+  fi.encoding = 1; fi.group_size_shift = 1; fi.gab = false; fi.epf_iters = 0;
+  BitWriter cs;
+  WriteCodestreamHeaders(ii, cs);
+  WriteFrameHeader(ii, fi, cs);
+  std::vector<std::vector<uint8_t>> sections;
+  if (single) {
+    lf_global.AppendBits(packed.data(), sec_bits[0]);   // the channels of a frame that fits one group belong to the global stream
+    sections.push_back(lf_global.Finish());
+  } else {
+    sections.push_back(lf_global.Finish());
+    for (int g = 0; g < im.nlf; g++) sections.emplace_back();   // no channel is small enough for the LF groups
+    sections.emplace_back();                                    // HfGlobal is empty in a Modular frame
+    for (int g = 0; g < im.ng; g++) sections.emplace_back(packed.begin() + off[g], packed.begin() + off[g + 1]);
+  }
+  std::vector<uint32_t> sizes;
+  for (auto& sec : sections) sizes.push_back((uint32_t)sec.size());
+  WriteToc(sizes, cs);
+  std::vector<uint8_t> codestream = cs.Finish();
+  for (auto& sec : sections) codestream.insert(codestream.end(), sec.begin(), sec.end());
+  EmitFile(codestream, md, io, progress);
+}
+
+void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const EncoderImageMetadata* md, IOCallbacks* io, ProgressProc progress) {
+  Arena A;
+  hipStream_t s = nullptr;
+  EncImage im;
+  BeginImage(bmp, md, A, im, progress);
+  const uint32_t w = bmp->width, h = bmp->height;
+  const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
   // ---- 2. quantiser and loop-filter parameters (only distance comes from the options, :319; effort is not used)
   const float distance = std::max(0.05f, std::min(25.0f, opt->distance));
   EncFrameInfo fi;
@@ -266,20 +375,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   WriteToc(sizes, cs);
   std::vector<uint8_t> codestream = cs.Finish();
   for (auto& sec : sections) codestream.insert(codestream.end(), sec.begin(), sec.end());
-  // ---- 8. container + output through the host callbacks (always boxes, Encoder/JxlEncoder.cpp:201)
-  std::vector<uint8_t> file = WriteContainer(codestream, md->exif, md->exifSize, md->xmp, md->xmpSize);
-  const size_t kChunk = 64 * 1024;   // OutputProcessor.cpp:16
-  size_t done = 0;
-  int last_pct = 30;
-  while (done < file.size()) {
-    const size_t n = std::min(kChunk, file.size() - done);
-    const int32_t st = HResultToStatus(io->Write(file.data() + done, n));
-    if (st != EncoderStatus_Ok) throw EncFail(st, st == EncoderStatus_WriteError ? "the output stream rejected a write" : "");
-    done += n;
-    const int pct = 30 + (int)(60.0 * done / file.size()) / 5 * 5;   // 30 -> 90 in steps of 5 (:340-344)
-    if (pct > last_pct) { Progress(progress, pct); last_pct = pct; }
-  }
-  Progress(progress, 95);
+  EmitFile(codestream, md, io, progress);
 }
 
 }  // namespace
@@ -293,9 +389,8 @@ extern "C" JXLFILETYPEIO_API EncoderStatus SaveImage(const BitmapData* bitmap, c
   try {
     Progress(progress, 0);   // :162
     if (!callbacks->Write) throw EncFail(EncoderStatus_NullParameter, "");
-    if (options->lossless)
-      throw EncFail(EncoderStatus_EncodeError, "lossless (Modular) encoding is not built on the MI355X path yet; lossy VarDCT only");
-    EncodeLossy(bitmap, options, metadata, callbacks, progress);
+    if (options->lossless) EncodeLossless(bitmap, metadata, callbacks, progress);   // :214,325
+    else EncodeLossy(bitmap, options, metadata, callbacks, progress);
     return EncoderStatus_Ok;
   } catch (const EncFail& e) {
     if (e.status == EncoderStatus_EncodeError) SetEncErr(err, e.what());

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
 __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
   const int g = blockIdx.x;
-  if (g >= im.ng) return;
+  if (g >= im.ng || im.is_modular) return;
   const int lane = threadIdx.x;
   const int gx = g % im.xg, gy = g / im.xg;
   const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   __shared__ int32_t s_carry[256];
   const DevImage& im = imgs[blockIdx.y];
   const int g = blockIdx.x;
-  if (!im.has_alpha || g >= im.ng) return;
+  if (!im.has_alpha || g >= im.ng || im.is_modular) return;
   const int lane = threadIdx.x;
   const ChanDesc d = im.alpha_desc[g];
   const int gx = g % im.xg, gy = g / im.xg;
@@ -1038,6 +1038,95 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
       const int v = cst ? d.value : plane[o];
       out[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
     }
+  }
+}
+
+// ------------------------------------------------------------------ Modular (lossless) frames
+// Phase A: one lane per group; every channel of the group's rectangle is one Modular channel of the group's stream.
+template <bool kLds>
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const SectionTask task = tasks[blockIdx.x];
+  const DevImage& im = imgs[task.image];
+  ModTables<kLds> mt;
+  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  const int lane = threadIdx.x;
+  if (lane >= task.count) return;
+  const int g = task.first + lane;
+  const int gd = im.group_dim;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int x0 = gx * gd, y0 = gy * gd;
+  const int gw = min(gd, im.w - x0), gh = min(gd, im.h - y0);
+  ChanDesc* desc = im.mod_desc + (size_t)g * 4;
+  // a frame that fits one group codes its channels in the GlobalModular stream (id 0) right after the header in LfGlobal
+  const int sec = im.single ? 0 : 2 + im.nlf + g;
+  const uint64_t start = im.single ? im.mod_data_bits : im.sec_off[sec] * 8;
+  const int sid = im.single ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  LaneBits b;
+  b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
+  uint32_t err = 0;
+  if (!im.single && b.Read(4) != 3) err |= kErrUnsupportedHeader;
+  if (!err) {
+    uint32_t state = b.Read(32);
+#pragma unroll 1
+    for (int c = 0; c < im.mod_nch; c++)
+      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, c, sid, gw, gh, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, desc + c);
+    if (state != 0x130000u || start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
+  }
+  if (err) {
+    ChanDesc d;
+    d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
+    for (int c = 0; c < 4; c++) desc[c] = d;
+    SetError(im, err);
+  }
+}
+
+// Phase B: one wavefront per (group, channel)
+__global__ __launch_bounds__(64) void modular_finish_kernel(const DevImage* imgs) {
+  __shared__ int32_t s_carry[kCarryInts];
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.is_modular) return;
+  const int g = blockIdx.x >> 2, c = blockIdx.x & 3;
+  if (g >= im.ng || c >= im.mod_nch) return;
+  const int gd = im.group_dim;
+  const int gx = g % im.xg, gy = g / im.xg;
+  const int x0 = gx * gd, y0 = gy * gd;
+  const int gw = min(gd, im.w - x0), gh = min(gd, im.h - y0);
+  const int sid = im.single ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  FinishChannelI32(im.mod_desc[(size_t)g * 4 + c], (const I4*)im.tree, c, sid, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, gw, gh,
+                   (JXL_LDS int32_t*)s_carry, threadIdx.x);
+}
+
+// Inverse reversible colour transforms (last first), clamp, interleave.
+__global__ void modular_out_kernel(const DevImage* imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.is_modular) return;
+  const size_t n = (size_t)im.w * im.h;
+  const int nch = im.mod_nch;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int32_t v[4] = {0, 0, 0, 0};
+    for (int c = 0; c < nch; c++) v[c] = im.mod_plane[c][i];
+    for (int t = im.mod_ntr - 1; t >= 0; t--) {
+      const int bc = im.mod_tr[t][0], type = im.mod_tr[t][1];
+      const int perm = type / 7, custom = type % 7;
+      int32_t a = bc == 0 ? v[0] : v[1], b = bc == 0 ? v[1] : v[2], c = bc == 0 ? v[2] : v[3];
+      if (custom == 6) {
+        const int32_t tmp = a - (c >> 1), G = c + tmp, B = tmp - (b >> 1), R = B + b;
+        a = R; b = G; c = B;
+      } else {
+        if (custom & 1) c += a;
+        if ((custom >> 1) == 1) b += a;
+        else if ((custom >> 1) == 2) b += (a + c) >> 1;
+      }
+      int32_t o[3];
+      o[perm % 3] = a;
+      o[(perm + 1 + perm / 3) % 3] = b;
+      o[(perm + 2 - perm / 3) % 3] = c;
+      if (bc == 0) { v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; }
+      else { v[1] = o[0]; v[2] = o[1]; v[3] = o[2]; }
+    }
+    uint8_t* out = im.out + i * nch;
+    for (int c = 0; c < nch; c++) out[c] = (uint8_t)(v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]));
   }
 }
 
@@ -1086,6 +1175,21 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
   } else {
     hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), 64 * kRingWords * 4, s, imgs, tasks, lane_stride);
   }
+}
+
+void LaunchModular(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_groups, size_t max_pixels,
+                   hipStream_t s) {
+  if (ntasks <= 0) return;
+  if (lds_bytes) {
+    RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
+    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks);
+  } else {
+    hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), 64 * kRingWords * 4, s, imgs, tasks);
+  }
+  hipLaunchKernelGGL(modular_finish_kernel, dim3(max_groups * 4, nimg), dim3(64), 0, s, imgs);
+  size_t b = (max_pixels + 255) / 256;
+  if (b > 8192) b = 8192;
+  hipLaunchKernelGGL(modular_out_kernel, dim3((unsigned)b, nimg), dim3(256), 0, s, imgs);
 }
 
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s) {

@@ -741,14 +741,25 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
     ReadTree(r, f, limit);
     ReadCode(r, (f.tree.size() + 1) / 2, f.mcode);
   }
-  // GlobalModular image header: only the layout {use_global_tree, default wp, no transforms} is decoded by the kernels.
+  // GlobalModular image header.  VarDCT frames: only {global tree, default predictor parameters, no transforms} (the alpha
+  // channel); Modular frames additionally allow reversible colour transforms.
   size_t nchan = (f.encoding == 1 ? f.ncolor : 0) + f.ec.size();
   f.global_modular_has_channels = nchan > 0;
   if (nchan > 0) {
     bool use_global = r.b(), wp_default = r.b();
-    uint32_t ntr = r.U32(V(0), V(1), B(4, 2), B(8, 18));
     REQUIRE(use_global && f.has_global_tree, "modular streams with local MA trees are not supported on the GPU path yet");
-    REQUIRE(wp_default && ntr == 0, "modular transforms / custom weighted-predictor headers are not supported on the GPU path yet");
+    REQUIRE(wp_default, "custom weighted-predictor parameters are not supported on the GPU path yet");
+    uint32_t ntr = r.U32(V(0), V(1), B(4, 2), B(8, 18));
+    REQUIRE(f.encoding == 1 || ntr == 0, "modular transforms on extra channels are not supported on the GPU path yet");
+    for (uint32_t i = 0; i < ntr; i++) {
+      ParsedFrame::ModTransform t;
+      t.id = r.u(2);
+      REQUIRE(t.id == 0, t.id == 2 ? "Squeeze transforms are not decoded on the GPU path yet" : "Palette transforms are not decoded on the GPU path yet");
+      t.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
+      t.rct_type = r.U32(V(6), B(2), B(4, 2), B(6, 10));
+      REQUIRE(t.rct_type < 42 && t.begin_c + 3 <= nchan, "reversible colour transform out of range");
+      f.mod_transforms.push_back(t);
+    }
   }
   REQUIRE(r.ok(), "truncated LfGlobal");
 }
@@ -1169,17 +1180,23 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   if (headers_only) return;
   if (f.bits != 8 || f.exp_bits != 0) Fail("only 8-bit integer samples are supported yet");
   if (f.encoding == 0 && !f.xyb_encoded) Fail("VarDCT frames without XYB are not supported yet");
-  if (f.encoding == 1) Fail("Modular (lossless) frames are not decoded on the GPU path yet");
+  if (f.encoding == 1 && f.xyb_encoded) Fail("lossy Modular (XYB) frames are not decoded on the GPU path yet");
+  if (f.encoding == 1 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u)) Fail("extra channels other than alpha are not supported yet");
   f.single = f.sec_off.size() == 1;
   {
     Bits s(f.cs + f.sec_off[0], f.sec_size[0]);
     ReadLfGlobal(s, f);
     // single-section frames: LfGlobal | LfGroup | HfGlobal | PassGroup share one bit stream; the kernels continue from here
     f.after_lf_global_bits = f.sec_off[0] * 8 + s.pos();
+    f.mod_data_bits = f.after_lf_global_bits;
   }
   if (f.tree_uses_wp || f.tree_uses_ref)
     Fail("MA trees using the weighted predictor or reference-channel properties are not supported on the GPU path yet");
   if (f.mcode.use_prefix || f.mcode.lz77) Fail("prefix-coded / LZ77 modular streams are not supported on the GPU path yet");
+  if (f.encoding == 1) {
+    if (!f.has_global_tree) Fail("Modular frames without a global MA tree are not supported on the GPU path yet");
+    return;   // nothing else is global in a Modular frame: every group section is decoded on the GPU
+  }
   // HfGlobal of a single-section frame starts where the GPU finishes the LF group (ParseHfGlobalAt); the two-phase
   // submission that needs is not wired into the batch pipeline yet, so say so instead of decoding garbage.
   if (f.single) Fail("single-group frames (<= 256x256) are not decoded on the GPU path yet");

@@ -98,6 +98,10 @@ struct ParsedFrame {
   bool tree_uses_wp = false, tree_uses_ref = false;
   HostCode mcode;
   bool global_modular_has_channels = false;
+  // Modular frames (encoding 1): the GlobalModular image header
+  struct ModTransform { uint32_t id = 0, begin_c = 0, rct_type = 0; };
+  std::vector<ModTransform> mod_transforms;   // only RCT is decoded on the GPU path so far
+  uint64_t mod_data_bits = 0;                 // codestream bit position of the GlobalModular channel data (stream 0)
   bool single = false;                 // one TOC entry: all sections share one bit stream (frames that fit one group)
   uint64_t after_lf_global_bits = 0;   // codestream bit position right after the host-parsed part of LfGlobal
   // ---- HfGlobal

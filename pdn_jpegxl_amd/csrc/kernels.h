@@ -14,6 +14,9 @@ void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int
                     const uint16_t* natural_orders_small, hipStream_t s);
 void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
+// Modular (lossless) frames: per-group ANS phase, predictor phase, inverse colour transforms + interleave
+void LaunchModular(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_groups, size_t max_pixels,
+                   hipStream_t s);
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,

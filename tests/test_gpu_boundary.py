@@ -42,4 +42,4 @@ def test_callback_failures_map_to_reference_statuses(oracle):
 def test_unsupported_streams_fail_loudly(oracle):
     with pytest.raises(api.FormatError) as e:
         api.load_image(oracle.encode(synth(300, 300, 4), lossless=True))
-    assert e.value.status == "DecodeError" and "Modular" in str(e.value)
+    assert e.value.status == "DecodeError" and "weighted predictor" in str(e.value)

@@ -1,0 +1,73 @@
+"""GPU tests of Modular (lossless) frames: bit-exact against the source pixels (the ground truth of a lossless codec) and against the
+oracle's decoder, for streams written by the oracle's encoder and by the product's own SaveImage(lossless)."""
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def bgra_of(rgba):
+    return np.ascontiguousarray(rgba[..., [2, 1, 0, 3]])
+
+
+@pytest.mark.parametrize("size", [(300, 280), (200, 100), (256, 256), (777, 531), (257, 1)])
+@pytest.mark.parametrize("layout", ["rgba", "rgb", "gray", "graya"])
+def test_oracle_lossless_streams_decode_bit_exact(oracle, size, layout):
+    w, h = size
+    img = synth(w, h, 21)
+    src = {"rgba": img, "rgb": img[..., :3], "gray": img[..., 1:2], "graya": img[..., [1, 3]]}[layout]
+    src = np.ascontiguousarray(src)
+    # local-gradient context tree (properties 10 / 11: the per-sample tree walk of the generic lane path), gradient predictor
+    data = oracle.encode(src, lossless=True, lossless_tree=1, lossless_predictor=5)
+    got = api.load_image(data)
+    assert got.pixels.shape == src.shape
+    assert (got.pixels == src).all()
+    assert (got.pixels == oracle.decode(data).pixels).all()
+
+
+@pytest.mark.parametrize("predictor", [0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13])
+def test_every_plain_predictor(oracle, predictor):
+    img = synth(300, 260, 23)
+    data = oracle.encode(img, lossless=True, lossless_tree=1, lossless_predictor=predictor)
+    assert (api.load_image(data).pixels == img).all()
+
+
+@pytest.mark.parametrize("size,seed", [((300, 280), 3), ((130, 90), 4), ((520, 400), 5)])
+def test_save_image_lossless_round_trip(oracle, size, seed):
+    w, h = size
+    img = synth(w, h, seed)
+    data = api.save_image(bgra_of(img), lossless=True)
+    assert (oracle.decode(data).pixels == img).all()          # the oracle reads the product's stream back exactly
+    got = api.load_image(data)
+    assert got.pixels.shape == img.shape and (got.pixels == img).all()
+    opaque = img.copy()
+    opaque[..., 3] = 255
+    data = api.save_image(bgra_of(opaque), lossless=True)
+    got = api.load_image(data)
+    assert got.pixels.shape == (h, w, 3) and (got.pixels == opaque[..., :3]).all()
+    gray = opaque.copy()
+    gray[..., 0] = gray[..., 2] = gray[..., 1]
+    got = api.load_image(api.save_image(bgra_of(gray), lossless=True))
+    assert got.pixels.shape == (h, w, 1) and (got.pixels[..., 0] == gray[..., 1]).all()
+
+
+def test_4k_lossless_bit_exact(oracle):
+    """BASELINE.json configs[4] shape: 3840x2160 Modular lossless decode, bit-exact check (Squeeze / weighted predictor: next)."""
+    img = synth(3840, 2160, 2)
+    data = api.save_image(bgra_of(img), lossless=True)
+    got = api.load_image(data)
+    assert got.pixels.shape == img.shape and (got.pixels == img).all()
+    rgb = np.ascontiguousarray(img[..., :3])
+    data = oracle.encode(rgb, lossless=True, lossless_tree=1, lossless_predictor=5)
+    assert (api.load_image(data).pixels == rgb).all()
+
+
+def test_corrupt_lossless_stream_is_reported(oracle):
+    data = bytearray(oracle.encode(synth(300, 280, 7), lossless=True, lossless_tree=1, lossless_predictor=5))
+    data[len(data) // 2] ^= 0x55
+    data[len(data) // 2 + 1] ^= 0xAA
+    with pytest.raises(api.JxlError):
+        api.load_image(bytes(data))

@@ -118,6 +118,8 @@ struct JxlHipDecoder {
   // options
   int lane_stride_override = 0;
   bool debug_taps = false;
+  // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
+  int band_first_row = 0, band_rows = 0;
   bool overlap = true;
 
   explicit JxlHipDecoder(int dev);
@@ -452,6 +454,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.wt = (f.w8 + 7) / 8; d.ht = (f.h8 + 7) / 8;
     d.xg = f.xg; d.yg = f.yg; d.ng = f.ng; d.xlf = f.xlf; d.ylf = f.ylf; d.nlf = f.nlf;
     d.ncolor = f.ncolor; d.has_alpha = f.alpha_index >= 0; d.nch_out = d.ncolor + d.has_alpha;
+    // band: group rows [b0, b1) are output; one more row each side is decoded for the loop-filter halo
+    int b0 = 0, b1 = (int)f.yg;
+    if (band_rows > 0 && f.encoding == 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
+    d.dec_gy0 = std::max(0, b0 - 1); d.dec_gy1 = std::min<int>((int)f.yg, b1 + 1);
+    d.band_y0 = std::min<int>(b0 * kGroupDim, (int)f.ysize); d.band_y1 = std::min<int>(b1 * kGroupDim, (int)f.ysize);
     d.to_srgb = f.color.all_default || (!f.color.have_gamma && f.color.tf == 13);
     auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h_blob + off, src, bytes); };
     put(l.sec_off, f.sec_off.data(), 8 * f.sec_off.size());
@@ -592,12 +599,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = lds_lf;
     max_groups = std::max<int>(max_groups, (int)f.ng);
-    for (uint32_t g = 0; g < f.nlf; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, f.nlf - g), 0};
-    for (uint32_t g = 0; g < f.nlf; g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
-    for (uint32_t g = 0; g < f.ng; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, f.ng - g), 0};
+    // LF groups that intersect the decoded group rows (8 group rows per LF group row); HF groups of the decoded rows; alpha of the band
+    const uint32_t lfy0 = (uint32_t)d.dec_gy0 / 8, lfy1 = ((uint32_t)d.dec_gy1 + 7) / 8;
+    for (uint32_t g = lfy0 * f.xlf; g < std::min<uint32_t>(f.nlf, lfy1 * f.xlf); g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
+    {
+      const uint32_t l0 = lfy0 * f.xlf, l1 = std::min<uint32_t>(f.nlf, lfy1 * f.xlf);
+      for (uint32_t g = l0; g < l1; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, l1 - g), 0};
+    }
+    const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
+    for (uint32_t g = hg0; g < hg1; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, hg1 - g), 0};
+    const uint32_t ag0 = (uint32_t)(d.band_y0 / kGroupDim) * f.xg, ag1 = (uint32_t)((d.band_y1 + kGroupDim - 1) / kGroupDim) * f.xg;
     if (d.has_alpha)
-      for (uint32_t g = 0; g < f.ng; g += per_alpha_wg)
-        alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, f.ng - g), 0};
+      for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
+        alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, ag1 - g), 0};
   }
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
   d_imgs = (DevImage*)(d_blob + off_imgs);
@@ -793,6 +807,8 @@ int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
   if (!dec || !name) return 0;
   if (!strcmp(name, "debug_taps")) { dec->debug_taps = value != 0; return 1; }
   if (!strcmp(name, "lane_stride")) { dec->lane_stride_override = value; return 1; }
+  if (!strcmp(name, "band_first_row")) { dec->band_first_row = value; return 1; }
+  if (!strcmp(name, "band_rows")) { dec->band_rows = value; return 1; }
   if (!strcmp(name, "overlap")) { dec->overlap = value != 0; return 1; }
   return 0;
 }

@@ -117,6 +117,10 @@ struct DevImage {
   uint64_t lf_start_bits;   // where the GPU starts (global alpha channel, then the LF group)
   uint64_t hf_start_bits;   // after HfGlobal (filled in once the host has parsed it)
   uint64_t* lf_end_bits;    // written by lf_group_kernel: bit position after the LF group
+  // Band-restricted decode of one large frame (multi-GPU sharding by group rows): groups of rows [dec_gy0, dec_gy1) are
+  // decoded (the band plus one halo row each side for the loop filters), pixel rows [band_y0, band_y1) are written to `out`,
+  // whose first row is band_y0.  A whole-frame decode has dec_gy0 = 0, dec_gy1 = yg, band = [0, h).
+  int32_t dec_gy0, dec_gy1, band_y0, band_y1;
   // Modular frames (lossless): up to 4 channels of the whole image, decoded per group (or, for a frame that fits one
   // group, from the GlobalModular stream), then inverse colour transforms and interleaving in modular_out_kernel
   int32_t is_modular, mod_nch, group_dim, mod_ntr;

@@ -1022,8 +1022,9 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   const int g = blockIdx.x;
   if (!im.has_alpha || g >= im.ng || im.is_modular) return;
   const int lane = threadIdx.x;
-  const ChanDesc d = im.alpha_desc[g];
   const int gx = g % im.xg, gy = g / im.xg;
+  if (gy * kGroupDim >= im.band_y1 || (gy + 1) * kGroupDim <= im.band_y0) return;   // outside the band: never decoded
+  const ChanDesc d = im.alpha_desc[g];
   const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
   const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
   int32_t* plane = im.alpha32 + (size_t)y0 * im.w + x0;

@@ -64,7 +64,7 @@ __global__ void cell_sigma_kernel(const DevImage* imgs) {
   const float kInvSigmaNum = -1.1715728752538099024f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const float sigma_quant = im.epf_quant_mul / (im.quant_scale * (float)im.rawq[i] * kInvSigmaNum);
-    float sigma = sigma_quant * im.epf_sharp_lut[im.sharp[i]];
+    float sigma = sigma_quant * im.epf_sharp_lut[im.sharp[i] & 7];   // & 7: cells outside a decoded band hold no sharpness yet
     sigma = fminf(-1e-4f, sigma);
     im.inv_sigma[i] = 1.0f / sigma;
   }

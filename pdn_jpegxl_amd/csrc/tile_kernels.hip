@@ -42,13 +42,14 @@ __device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, flo
   float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
   if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
-  const size_t i = (size_t)y * im.w + x;
+  const size_t i = (size_t)y * im.w + x;                       // position in the frame (alpha plane)
+  const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.nch_out == 4) {
     uchar4 px;
     px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = im.alpha[i];
-    ((uchar4*)im.out)[i] = px;
+    ((uchar4*)im.out)[o] = px;
   } else {
-    uint8_t* out = im.out + i * im.nch_out;
+    uint8_t* out = im.out + o * im.nch_out;
     if (im.ncolor == 3) {
       out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
     } else {
@@ -86,6 +87,7 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
   if (ablate & 16) return;
   const int tid = threadIdx.x;
   const int tx = tile % im.wt, ty = tile / im.wt;
+  if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
   int bad = 0;
   if (tid < 64) {
     const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
@@ -287,6 +289,10 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
   if ((int)blockIdx.x >= tiles_x * tiles_y) return;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
   const int x0 = tx * TW, y0 = ty * TH;
+  // Band decode: the last stage writes exactly the band; earlier stages also produce the rows later stages read (<= 8)
+  const bool final_stage = im.final_stage == kStage;
+  const int row_lo = final_stage ? im.band_y0 : max(0, im.band_y0 - 8), row_hi = final_stage ? im.band_y1 : min(h, im.band_y1 + 8);
+  if (y0 + TH <= row_lo || y0 >= row_hi) return;
   const float* in0 = im.stage_in[kStage][0];
   const float* in1 = im.stage_in[kStage][1];
   const float* in2 = im.stage_in[kStage][2];
@@ -304,12 +310,11 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
     t[2][ly][lx] = v2;
   }
   __syncthreads();
-  const bool final_stage = im.final_stage == kStage;
 #pragma unroll 2
   for (int e = threadIdx.x; e < TW * TH; e += 256) {
     const int ly = e / TW, lx = e % TW;
     const int x = x0 + lx, y = y0 + ly;
-    if (x >= w || y >= h) continue;
+    if (x >= w || y < row_lo || y >= row_hi) continue;
     const int cy = ly + HALO, cx = lx + HALO;
     float o0, o1, o2;
     if (kStage == 0) {
@@ -372,9 +377,9 @@ __global__ void out_only_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
   if (im.final_stage != 4) return;
   const int w = im.w, wp = im.wp;
-  const size_t n = (size_t)w * im.h;
+  const size_t n = (size_t)w * (im.band_y1 - im.band_y0);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const int x = (int)(i % w), y = (int)(i / w);
+    const int x = (int)(i % w), y = im.band_y0 + (int)(i / w);
     const size_t o = (size_t)y * wp + x;
     WritePixel(im, x, y, im.stage_in[4][0][o], im.stage_in[4][1][o], im.stage_in[4][2][o]);
   }

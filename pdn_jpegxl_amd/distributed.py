@@ -33,3 +33,38 @@ def gather_bands(band, rows_per_rank, row_bytes, dst=0):
     if rank != dst:
         return None
     return torch.cat([p[: r * row_bytes] for p, r in zip(parts, rows_per_rank)])
+
+
+def decode_frame_band(dec, data, rank, world, device="cuda"):
+    """Band-sharded decode of ONE large lossy frame: this rank decodes the group rows band_rows() assigns to it (plus one halo
+    row each side, redundantly, so the loop filters need no exchange) and returns (uint8 tensor of its pixel rows, (y0, y1)).
+    `dec` is a pdn_jpegxl_amd.api.Decoder bound to this rank's GPU."""
+    from . import api
+    info = api.peek(data)
+    n_rows = (info.height + 255) // 256
+    r0, r1 = band_rows(n_rows, rank, world)
+    y0, y1 = min(r0 * 256, info.height), min(r1 * 256, info.height)
+    out = torch.empty(max(1, (y1 - y0) * info.width * info.num_channels), dtype=torch.uint8, device=device)
+    if r1 > r0:
+        dec.set_option("band_first_row", r0)
+        dec.set_option("band_rows", r1 - r0)
+        try:
+            st = dec.decode_batch([data], [out.data_ptr()], None, synchronize=True)
+        finally:
+            dec.set_option("band_rows", 0)
+        if st[0] != 0:
+            raise RuntimeError("band decode failed with status %d" % st[0])
+    return out[: (y1 - y0) * info.width * info.num_channels], (y0, y1)
+
+
+def decode_frame_sharded(dec, data, dst=0):
+    """All ranks decode their band of `data`; the bands are gathered (RCCL all-gather over xGMI) and rank `dst` gets the image."""
+    from . import api
+    rank, world = dist.get_rank(), dist.get_world_size()
+    info = api.peek(data)
+    band, _ = decode_frame_band(dec, data, rank, world)
+    n_rows = (info.height + 255) // 256
+    spans = [band_rows(n_rows, r, world) for r in range(world)]
+    rows = [min(b * 256, info.height) - min(a * 256, info.height) for a, b in spans]
+    img = gather_bands(band, rows, info.width * info.num_channels, dst=dst)
+    return None if img is None else img.reshape(info.height, info.width, info.num_channels)

@@ -160,3 +160,25 @@ def test_corrupt_stream_is_reported_not_crashing(gpu_decoder, oracle):
     with pytest.raises(api.FormatError) as e:
         gpu_decoder.decode_batch([bytes(data)], [out.data_ptr()])
     assert e.value.status == "DecodeError"
+
+
+# ---------------------------------------------------------------- band-sharded decode of one frame (multi-GPU layout)
+@pytest.mark.parametrize("distance,world", [(1.0, 2), (1.0, 3), (4.5, 2), (4.5, 8)])
+def test_band_decode_equals_whole_frame(oracle, gpu_decoder, distance, world):
+    """Every rank's band (decoded with one redundant halo group row each side) must be bit-identical to the same rows of the
+    whole-frame decode: Gaborish + up to three EPF iterations read across the band boundary.  The ranks are emulated one after
+    another on the one GPU of the test box; the gather itself is covered by the gloo test in test_distributed.py."""
+    import torch
+    from pdn_jpegxl_amd.distributed import decode_frame_band
+    img = synth(520, 1400, 31)          # 3 x 6 groups
+    data = oracle.encode(img, distance=distance)
+    whole = torch.empty(img.size, dtype=torch.uint8, device="cuda")
+    assert gpu_decoder.decode_batch([data], [whole.data_ptr()]) == [0]
+    whole = whole.cpu().numpy().reshape(img.shape)
+    rows = 0
+    for rank in range(world):
+        band, (y0, y1) = decode_frame_band(gpu_decoder, data, rank, world)
+        got = band.cpu().numpy().reshape(y1 - y0, img.shape[1], 4)
+        assert (got == whole[y0:y1]).all(), (rank, y0, y1)
+        rows += y1 - y0
+    assert rows == img.shape[0]

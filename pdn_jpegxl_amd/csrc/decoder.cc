@@ -320,7 +320,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t mod_plane[4], mod_desc;
+    size_t mod_plane[4], mod_desc, wp_lf, wp_grp;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
@@ -344,6 +344,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       const int nch = f.ncolor + (f.alpha_index >= 0 ? 1 : 0);
       for (int c = 0; c < nch; c++) l.mod_plane[c] = ws.Take(4 * (size_t)f.xsize * f.ysize);
       l.mod_desc = ws.Take((size_t)f.ng * 4 * sizeof(ChanDesc));
+      if (f.tree_uses_wp) l.wp_grp = ws.Take((size_t)f.ng * 10 * (f.group_dim + 2) * 4);
       n_mod_tasks += ((int)f.ng + 63) / 64;
       continue;
     }
@@ -374,6 +375,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); }
     l.inv_sigma = ws.Take(4 * cells);
     l.alpha = ws.Take((size_t)f.xsize * f.ysize);
+    if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
     total_lf += f.nlf;
     total_groups += f.ng;
   }
@@ -503,6 +505,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (int t = 0; t < d.mod_ntr; t++) { d.mod_tr[t][0] = (int32_t)f.mod_transforms[t].begin_c; d.mod_tr[t][1] = (int32_t)f.mod_transforms[t].rct_type; }
       for (int c = 0; c < d.mod_nch; c++) d.mod_plane[c] = (int32_t*)(wr + l.mod_plane[c]);
       d.mod_desc = (ChanDesc*)(wr + l.mod_desc);
+      if (f.tree_uses_wp) { d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * ((int64_t)f.group_dim + 2); }
       d.status = (uint32_t*)(wz + l.z_status);
       status_off[i] = l.z_status;
       d.out = dev_out[i];
@@ -569,6 +572,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.alpha32 = (int32_t*)d.tmp[0];
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
+    if (f.tree_uses_wp) { d.wp_lf = (int32_t*)(wr + l.wp_lf); d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * (kGroupDim + 2); }
     d.out = dev_out[i];
     // stage routing (ping-pong between xyb and xyb2)
     float** cur = d.xyb;

@@ -128,6 +128,10 @@ struct DevImage {
   int32_t* mod_plane[4];    // w*h each
   ChanDesc* mod_desc;       // per group: 4 entries
   uint64_t mod_data_bits;   // single-group frames: bit position of the channel data inside LfGlobal
+  // weighted-predictor state (only allocated when the MA tree references it): lane-private scratch per LF group / per group
+  int32_t* wp_lf;           // [nlf][kWpLfInts]
+  int32_t* wp_grp;          // [ng][wp_grp_ints]
+  int64_t wp_grp_ints;
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
   int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
   float* tmp[3];            // wp*hp
@@ -146,6 +150,7 @@ struct DevImage {
 };
 
 constexpr int kBinfoInts = 2 * 1024 + 2 * 65536 + 65536;
+constexpr int kWpLfInts = 10 * (65536 + 2);   // widest channel of an LF group section: the block-info rows
 
 struct SectionTask {   // one workgroup's share of sections of one image
   int32_t image;

@@ -257,12 +257,84 @@ __device__ __forceinline__ void LeafRow(LaneBits& b, uint32_t& state, const Code
   }
 }
 
+// ------------------------------------------------------------------ weighted ("self-correcting") predictor, default parameters
+// Per-channel state in a lane-private global scratch: the true error and the four sub-predictor errors of the current
+// and the previous row ((w + 2) entries each), exactly as the format defines them.
+struct WpState {
+  JXL_GLB int32_t* err;        // [2][w + 2]
+  JXL_GLB uint32_t* pe;        // [4][2][w + 2]
+  int w2;                      // w + 2
+  int64_t prediction[4];
+  int64_t pred;
+  __device__ void Init(int32_t* scratch, int w) {
+    w2 = w + 2;
+    err = G(scratch);
+    pe = (JXL_GLB uint32_t*)(err + 2 * w2);
+    for (int i = 0; i < 10 * w2; i++) err[i] = 0;
+  }
+  static __device__ __forceinline__ uint32_t Div(uint32_t i) { return (1u << 24) / (i + 1); }
+  static __device__ __forceinline__ uint32_t ErrorWeight(uint64_t x, uint32_t maxweight) {
+    int shift = (63 - __clzll((long long)(x + 1))) - 5;
+    if (shift < 0) shift = 0;
+    return 4 + (uint32_t)((maxweight * (uint64_t)Div((uint32_t)(x >> shift))) >> shift);
+  }
+  static __device__ __forceinline__ int64_t Abs(int64_t v) { return v < 0 ? -v : v; }
+  __device__ int64_t Predict(int x, int y, int w, int64_t N, int64_t W, int64_t NE, int64_t NW, int64_t NN, int64_t* max_err) {
+    const int cur = (y & 1) ? 0 : w2, prev = (y & 1) ? w2 : 0;
+    const int pN = prev + x, pNE = x < w - 1 ? pN + 1 : pN, pNW = x > 0 ? pN - 1 : pN;
+    const uint32_t kW[4] = {13, 12, 12, 12};
+    uint32_t weights[4];
+    for (int i = 0; i < 4; i++) {
+      const JXL_GLB uint32_t* p = pe + (size_t)i * 2 * w2;
+      weights[i] = ErrorWeight((uint64_t)p[pN] + p[pNE] + p[pNW], kW[i]);
+    }
+    N <<= 3; W <<= 3; NE <<= 3; NW <<= 3; NN <<= 3;
+    const int64_t teW = x == 0 ? 0 : err[cur + x - 1], teN = err[pN], teNW = err[pNW], teNE = err[pNE];
+    const int64_t sumWN = teN + teW;
+    int64_t p = teW;
+    if (Abs(teN) > Abs(p)) p = teN;
+    if (Abs(teNW) > Abs(p)) p = teNW;
+    if (Abs(teNE) > Abs(p)) p = teNE;
+    *max_err = p;
+    prediction[0] = W + NE - N;
+    prediction[1] = N - (((sumWN + teNE) * 16) >> 5);
+    prediction[2] = W - (((sumWN + teNW) * 10) >> 5);
+    prediction[3] = N - ((teNW * 7 + teN * 7 + teNE * 7) >> 5);
+    uint32_t weight_sum = weights[0] + weights[1] + weights[2] + weights[3];
+    const int log_weight = 31 - __clz(weight_sum);
+    weight_sum = 0;
+    for (int i = 0; i < 4; i++) { weights[i] >>= log_weight - 4; weight_sum += weights[i]; }
+    int64_t sum = (int64_t)(weight_sum >> 1) - 1;
+    for (int i = 0; i < 4; i++) sum += prediction[i] * (int64_t)weights[i];
+    pred = (sum * (int64_t)Div(weight_sum - 1)) >> 24;
+    if (((teN ^ teW) | (teN ^ teNW)) > 0) return (pred + 3) >> 3;
+    const int64_t mx = W > NE ? (W > N ? W : N) : (NE > N ? NE : N), mn = W < NE ? (W < N ? W : N) : (NE < N ? NE : N);
+    pred = pred < mn ? mn : (pred > mx ? mx : pred);
+    return (pred + 3) >> 3;
+  }
+  __device__ void Update(int64_t val, int x, int y) {
+    const int cur = (y & 1) ? 0 : w2, prev = (y & 1) ? w2 : 0;
+    val <<= 3;
+    err[cur + x] = (int32_t)(pred - val);
+    for (int i = 0; i < 4; i++) {
+      const uint32_t e = (uint32_t)((Abs(prediction[i] - val) + 3) >> 3);
+      JXL_GLB uint32_t* p = pe + (size_t)i * 2 * w2;
+      p[cur + x] = e;
+      p[prev + x + 1] += e;
+    }
+  }
+};
+
 // Decodes one channel (w x h) into `out` (row stride `stride`).  Every property 0..14 and every predictor
 // except the weighted one are supported; the host rejects trees that need more.
 template <bool kLds>
 __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan,
-                               int stream_id, int w, int h, int32_t* out_generic, int stride, const RowBuf<kLds>& rbuf) {
+                               int stream_id, int w, int h, int32_t* out_generic, int stride, const RowBuf<kLds>& rbuf,
+                               int32_t* wp_scratch = nullptr) {
   JXL_GLB int32_t* const out = G(out_generic);
+  const bool use_wp = wp_scratch != nullptr;   // the tree references the weighted predictor: its state follows every sample
+  WpState wp;
+  if (use_wp) wp.Init(wp_scratch, w);
   int root = 0;
   for (;;) {
     const DevTreeNode nd = NodeOf(tree[root]);
@@ -291,7 +363,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
         rroot = v > nd.splitval ? nd.a : nd.b;
       }
       row_leaf = leaf.property < 0;
-      if (row_leaf) {
+      if (row_leaf && !use_wp) {
         const uint32_t lp = leaf.a & 0xFF;
         if (lp == 0 || lp == 1 || lp == 2 || lp == 5) {
           if (lp == 0) LeafRow<kLds, 0>(b, state, tab, leaf, w, y, row, stride, rb, rs, use_rb);
@@ -309,6 +381,11 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
     }
     if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
     const int32_t NE = (x + 1 < w && y) ? (use_rb ? rb[(x + 1) * rs] : prow[x + 1]) : N;
+    int64_t wp_pred = 0, wp_err = 0;
+    if (use_wp) {
+      const int32_t NNw = y > 1 ? prow[x - stride] : N;
+      wp_pred = wp.Predict(x, y, w, N, W, NE, NW, NNw, &wp_err);
+    }
     DevTreeNode nd = leaf;
     if (!row_leaf) {
       int node = rroot;
@@ -331,6 +408,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
           case 12: p = (int64_t)N - NE; break;
           case 13: { const int32_t NN = y > 1 ? prow[x - stride] : N; p = (int64_t)N - NN; break; }
           case 14: p = (int64_t)W - WW; break;
+          case 15: p = wp_err; break;
           default: p = 0; break;
         }
         node = p > nd.splitval ? nd.a : nd.b;
@@ -356,6 +434,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
         guess = gr < mn ? mn : (gr > mx ? mx : gr);
         break;
       }
+      case 6: guess = wp_pred; break;
       case 7: guess = NE; break;
       case 8: guess = NW; break;
       case 9: guess = WW; break;
@@ -373,6 +452,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
     const uint32_t tok = AnsGet(b, state, tab, ctx);
     const int32_t val = (int32_t)((int64_t)UnpackSigned(tok) * (int64_t)nd.b + nd.splitval + guess);
     row[x] = val;
+    if (use_wp) wp.Update(val, x, y);
     if (use_rb) rb[x * rs] = val;   // slot x held prev[x], which now lives in N
     prev9 = (int64_t)W + N - NW;
     const int32_t oldW = W;
@@ -436,18 +516,19 @@ __device__ int ClassifyChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree
 // Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
 template <bool kLds>
 __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
-                                  int w, int h, int32_t* out_generic, int stride, ChanDesc* desc) {
+                                  int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr) {
   ChanDesc d;
   d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
   if (w <= 0 || h <= 0) { *desc = d; return; }
   bool needs_n = false;
   int32_t cval = 0;
-  const int cls = ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
+  // a tree that references the weighted predictor anywhere keeps every channel on the generic path (its state is per sample)
+  const int cls = wp_scratch ? 0 : ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
   if (cls == 2) { d.kind = kChanConst; d.value = cval; *desc = d; return; }
   if (cls == 0) {
     RowBuf<kLds> rbuf;
     rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
-    ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf);
+    ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf, wp_scratch);
     *desc = d;
     return;
   }
@@ -596,10 +677,11 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   LaneBits b;
   b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
   uint32_t state = 0, err = 0, count = 1;
+  int32_t* const wps = im.wp_lf ? im.wp_lf + (size_t)g * kWpLfInts : nullptr;
   if (im.single && im.alpha_in_global) {
     // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
     state = b.Read(32);
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc, wps);
     if (state != 0x130000u) err |= kErrBitstream;
   }
   if (!err) {
@@ -629,7 +711,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
       else if (i == 5) { w = (int)count; h = 2; stride = (int)count; out = scratch + 2048; }
       else { w = bw; h = bh; stride = bw; out = scratch + 2048 + 2 * 65536; }
     }
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, desc + i);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, desc + i, wps);
   }
   if (!err && (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
   if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
@@ -1003,7 +1085,8 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
     const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
     const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
     const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc,
+                            im.wp_grp ? im.wp_grp + (size_t)g * im.wp_grp_ints : nullptr);
     if (state != 0x130000u) err |= kErrBitstream;
     if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
@@ -1071,7 +1154,8 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
     uint32_t state = b.Read(32);
 #pragma unroll 1
     for (int c = 0; c < im.mod_nch; c++)
-      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, c, sid, gw, gh, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, desc + c);
+      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, c, sid, gw, gh, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, desc + c,
+                              im.wp_grp ? im.wp_grp + (size_t)g * im.wp_grp_ints : nullptr);
     if (state != 0x130000u || start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
   if (err) {

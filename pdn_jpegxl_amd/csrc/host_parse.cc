@@ -1190,8 +1190,7 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
     f.after_lf_global_bits = f.sec_off[0] * 8 + s.pos();
     f.mod_data_bits = f.after_lf_global_bits;
   }
-  if (f.tree_uses_wp || f.tree_uses_ref)
-    Fail("MA trees using the weighted predictor or reference-channel properties are not supported on the GPU path yet");
+  if (f.tree_uses_ref) Fail("MA trees using reference-channel properties (16 and up) are not supported on the GPU path yet");
   if (f.mcode.use_prefix || f.mcode.lz77) Fail("prefix-coded / LZ77 modular streams are not supported on the GPU path yet");
   if (f.encoding == 1) {
     if (!f.has_global_tree) Fail("Modular frames without a global MA tree are not supported on the GPU path yet");

@@ -28,6 +28,20 @@ def test_oracle_lossless_streams_decode_bit_exact(oracle, size, layout):
     assert (got.pixels == oracle.decode(data).pixels).all()
 
 
+@pytest.mark.parametrize("size", [(300, 280), (200, 100), (777, 531)])
+@pytest.mark.parametrize("layout", ["rgba", "gray"])
+def test_weighted_predictor_streams_decode_bit_exact(oracle, size, layout):
+    """The oracle's default lossless mode: contexts from the weighted predictor's error (property 15) and the weighted predictor
+    itself (predictor 6) - the configuration libjxl uses for photographic content."""
+    w, h = size
+    img = synth(w, h, 29)
+    src = np.ascontiguousarray(img if layout == "rgba" else img[..., 1:2])
+    for pred in (6, 5):
+        data = oracle.encode(src, lossless=True, lossless_predictor=pred)
+        got = api.load_image(data)
+        assert got.pixels.shape == src.shape and (got.pixels == src).all(), pred
+
+
 @pytest.mark.parametrize("predictor", [0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13])
 def test_every_plain_predictor(oracle, predictor):
     img = synth(300, 260, 23)

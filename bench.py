@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "16")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "192")))
     ap.add_argument("--lane-stride", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="synchronise after every step (no cross-batch overlap)")
@@ -134,7 +134,7 @@ def main():
     if rank == 0:
         mp = W * H / 1e6
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        kernels = {"lf_ans": "lf_ans_kernel", "hf_decode": "hf_decode_kernel", "alpha_ans": "alpha_ans_kernel"}
+        kernels = {"lf_ans": "lf_ans_kernel", "hf_decode": "hf_decode_kernel", "alpha": "alpha_ans_kernel"}
         dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))   # the dominant kernel of this run
         dom_ms = stage_ms.get(dom, 0.0)
         alg_bytes = B * (len(data) + W * H * C)

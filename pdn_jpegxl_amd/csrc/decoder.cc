@@ -133,6 +133,7 @@ struct JxlHipDecoder {
               uint8_t* const* dev_out, hipStream_t stream, bool sync, DecoderStatus* statuses, ErrorInfo* err);
   DecoderStatus Finish(DecoderStatus* statuses, ErrorInfo* err);
   void CopyPlaneTap(int stage);
+  void PrepassSingle(ParsedFrame& f, const uint8_t* dev_file);
 };
 
 JxlHipDecoder::JxlHipDecoder(int dev) {
@@ -313,6 +314,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (auto& t : th) t.join();
     }
   }
+  // frames that fit one group: their HfGlobal can only be located once the LF group has been decoded (one bit stream)
+  for (int i = 0; i < n; i++) {
+    if (parse_status[i] != DecoderStatus_Ok || !frames[i].single || frames[i].encoding != 0) continue;
+    try {
+      PrepassSingle(frames[i], dev_data ? dev_data[i] : nullptr);
+    } catch (const ParseError& e) {
+      parse_status[i] = e.status;
+      parse_msg[i] = e.what();
+    } catch (const std::exception& e) {
+      parse_status[i] = DecoderStatus_DecodeError;
+      parse_msg[i] = e.what();
+    }
+  }
   // images that failed to parse are skipped on the device (their DevImage stays zeroed, ng = 0)
   // ---- 2. layout of blob and workspace
   Bump blob, ws_zero, ws;
@@ -320,7 +334,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t mod_plane[4], mod_desc, wp_lf, wp_grp;
+    size_t mod_plane[4], mod_desc, wp_lf, wp_grp, lf_end;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L(n);
@@ -375,6 +389,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); }
     l.inv_sigma = ws.Take(4 * cells);
     l.alpha = ws.Take((size_t)f.xsize * f.ysize);
+    l.lf_end = ws.Take(8);
     if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
     total_lf += f.nlf;
     total_groups += f.ng;
@@ -391,6 +406,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
     while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
+    // measured (MI355X, 4K frames): once a batch holds thousands of sections, fully packed wavefronts win - the workgroups of
+    // this kernel pin ~50 KB of tables in LDS each, and fewer of them leave more CUs to the concurrent pixel stages
+    if (total_groups >= 8192) lane_stride = 1;
   }
   const int per_wg = 256 / lane_stride;
   int n_pass_wg = 0;
@@ -407,6 +425,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (int i = 0; i < n; i++)
       if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
     while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
+    if (alpha_sections >= 8192) alpha_stride = 1;
   }
   const int per_alpha_wg = 64 / alpha_stride;
   int n_alpha_wg = 0;
@@ -432,7 +451,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   imgs.assign(n, DevImage());
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_lf = 0, lds_alpha = 0;
-  bool any_gab = false, any_alpha = false, any_unfiltered = false;
+  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
@@ -572,6 +591,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.alpha32 = (int32_t*)d.tmp[0];
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
+    d.lf_end_bits = (uint64_t*)(wr + l.lf_end);
+    if (f.single) {
+      d.single = 1;
+      d.alpha_in_global = d.has_alpha;
+      d.lf_start_bits = f.after_lf_global_bits;
+      d.hf_start_bits = f.hf_start_bits;
+    }
     if (f.tree_uses_wp) { d.wp_lf = (int32_t*)(wr + l.wp_lf); d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * (kGroupDim + 2); }
     d.out = dev_out[i];
     // stage routing (ping-pong between xyb and xyb2)
@@ -589,12 +615,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.final_stage = 4;
     for (int s = 0; s < 4; s++) if (d.stage_on[s]) d.final_stage = s;
     if (debug_taps) d.final_stage = 4;   // keep the filtered float planes for the stage taps; out_only_kernel converts
+    // the common configuration (Gaborish + one EPF iteration) runs as ONE kernel: the Gaborish result never leaves LDS
+    d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : 0;
+    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = 0; d.final_stage = 5; any_fused = true; }
     any_unfiltered |= d.final_stage == 4;
     max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
     max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));
-    any_gab |= f.gab;
+    any_gab |= f.gab && !d.fused_gab_epf1;
     any_alpha |= d.has_alpha != 0;
-    max_epf = std::max<int>(max_epf, f.epf_iters);
+    if (!d.fused_gab_epf1) max_epf = std::max<int>(max_epf, f.epf_iters);
     max_cells = std::max(max_cells, (size_t)f.w8 * f.h8);
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
@@ -642,21 +671,23 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_hf <= kLdsMax ? lds_hf : 0, d_natural_small,
                  s_hf);
   Mark("hf_decode", s_hf, 1);
+  // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
+  // nothing but the bandwidth-bound pixel stages
+  if (any_alpha)
+    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, s_hf);
+  if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
+  if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
+  Mark("alpha", s_hf, 1);
   if (s_hf != stream) {
     HIP_OK(hipEventRecord(S.hf_done, s_hf));
     HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
   }
   Mark("main_start", stream, 2);
-  if (any_alpha)
-    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, stream);
-  Mark("alpha_ans", stream, 2);
-  if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
-  if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, stream);
   LaunchReconTiles(d_imgs, n, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
   LaunchGenericReconstruct(d_imgs, n, d_basis_all, d_basis_small, d_llf_scale, stream);
   Mark("reconstruct", stream, 2);
   if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
-  LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, stream);
+  LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, stream);
   Mark("filters+output", stream, 2);
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
@@ -682,6 +713,82 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   } else if (statuses) {
     for (int i = 0; i < n; i++) statuses[i] = parse_status[i];
   }
+}
+
+// LF stage of ONE single-section frame on temporary buffers, synchronously: yields the bit position where HfGlobal starts,
+// which the host then parses (ParseHfGlobalAt).  The main pass decodes the (tiny) LF group again with everything in place.
+void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
+  Bump b;
+  const size_t cells = (size_t)f.w8 * f.h8;
+  const size_t o_img = b.Take(sizeof(DevImage)), o_task = b.Take(sizeof(SectionTask));
+  const size_t o_secoff = b.Take(8 * f.sec_off.size()), o_secsize = b.Take(4 * f.sec_size.size());
+  const size_t o_tree = b.Take(sizeof(DevTreeNode) * f.tree.size());
+  const size_t o_cmap = b.Take(f.mcode.ctx_map.size()), o_cfg = b.Take(4 * f.mcode.cfg.size()), o_alias = b.Take(8 * f.mcode.alias.size());
+  const bool resident = dev_file && f.cs_contiguous;
+  const size_t o_cs = resident ? 0 : b.Take(f.cs_size + 16);
+  const size_t upload = b.off;
+  const size_t o_status = b.Take(64), o_end = b.Take(8), o_count = b.Take(4), o_extra = b.Take(4), o_desc = b.Take(8 * sizeof(ChanDesc));
+  const size_t o_adesc = b.Take(sizeof(ChanDesc));
+  const size_t zero_end = b.off;
+  size_t o_lfq[3];
+  for (int c = 0; c < 3; c++) o_lfq[c] = b.Take(4 * cells);
+  const size_t o_binfo = b.Take((size_t)kBinfoInts * 4);
+  const size_t o_alpha = b.Take(4 * (size_t)f.xsize * f.ysize);
+  const size_t o_wp = f.tree_uses_wp ? b.Take((size_t)kWpLfInts * 4) : 0;
+  uint8_t* d = nullptr;
+  HIP_OK(hipMalloc(&d, b.off));
+  std::vector<uint8_t> h(upload, 0);
+  DevImage im;
+  memset(&im, 0, sizeof(im));
+  im.w = f.xsize; im.h = f.ysize; im.w8 = f.w8; im.h8 = f.h8; im.xlf = im.ylf = im.nlf = 1; im.xg = im.yg = im.ng = 1;
+  im.has_alpha = f.alpha_index >= 0;
+  im.single = 1; im.alpha_in_global = im.has_alpha;
+  im.lf_start_bits = f.after_lf_global_bits;
+  im.cs = resident ? dev_file + f.cs_file_offset : d + o_cs;
+  im.cs_size = f.cs_size;
+  im.sec_off = (const uint64_t*)(d + o_secoff); im.sec_size = (const uint32_t*)(d + o_secsize);
+  im.tree = (const DevTreeNode*)(d + o_tree); im.tree_size = (int32_t)f.tree.size();
+  im.mcode.ctx_map = d + o_cmap; im.mcode.cfg = (const uint32_t*)(d + o_cfg); im.mcode.alias = (const uint64_t*)(d + o_alias);
+  im.mcode.num_ctx = (uint32_t)f.mcode.ctx_map.size(); im.mcode.num_clusters = f.mcode.num_hist; im.mcode.log_alpha = f.mcode.log_alpha;
+  im.status = (uint32_t*)(d + o_status); im.lf_end_bits = (uint64_t*)(d + o_end); im.lf_count = (uint32_t*)(d + o_count);
+  im.lf_extra = d + o_extra; im.lf_desc = (ChanDesc*)(d + o_desc); im.alpha_desc = (ChanDesc*)(d + o_adesc);
+  for (int c = 0; c < 3; c++) im.lfq[c] = (int32_t*)(d + o_lfq[c]);
+  im.binfo = (int32_t*)(d + o_binfo); im.alpha32 = (int32_t*)(d + o_alpha);
+  if (f.tree_uses_wp) im.wp_lf = (int32_t*)(d + o_wp);
+  memcpy(h.data() + o_img, &im, sizeof(im));
+  const SectionTask task{0, 0, 1, 0};
+  memcpy(h.data() + o_task, &task, sizeof(task));
+  memcpy(h.data() + o_secoff, f.sec_off.data(), 8 * f.sec_off.size());
+  memcpy(h.data() + o_secsize, f.sec_size.data(), 4 * f.sec_size.size());
+  memcpy(h.data() + o_tree, f.tree.data(), sizeof(DevTreeNode) * f.tree.size());
+  memcpy(h.data() + o_cmap, f.mcode.ctx_map.data(), f.mcode.ctx_map.size());
+  {
+    std::vector<uint32_t> cfgp(f.mcode.cfg.size());
+    for (size_t k = 0; k < cfgp.size(); k++) {
+      cfgp[k] = f.mcode.cfg[k].split | f.mcode.cfg[k].msb << 4 | f.mcode.cfg[k].lsb << 8;
+      const uint64_t e0 = f.mcode.alias[k << f.mcode.log_alpha];
+      const uint32_t x0 = (uint32_t)e0, y0 = (uint32_t)(e0 >> 32);
+      if ((x0 >> 16) == 0 && (y0 >> 16) == 4096) cfgp[k] |= 1u << 12 | ((x0 >> 8) & 0xFF) << 16;
+    }
+    memcpy(h.data() + o_cfg, cfgp.data(), 4 * cfgp.size());
+  }
+  memcpy(h.data() + o_alias, f.mcode.alias.data(), 8 * f.mcode.alias.size());
+  if (!resident) memcpy(h.data() + o_cs, f.cs, f.cs_size);
+  hipError_t e = hipMemcpy(d, h.data(), upload, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d + upload, 0, zero_end - upload);
+  uint32_t st_words[16] = {0};
+  uint64_t lf_end = 0;
+  if (e == hipSuccess) {
+    const size_t lds = 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + 8 + 8 * f.mcode.alias.size() + 4 * f.mcode.cfg.size() + f.mcode.ctx_map.size();
+    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, lds <= 150 * 1024 ? lds : 0, own_stream);
+    e = hipStreamSynchronize(own_stream);
+  }
+  if (e == hipSuccess) e = hipMemcpy(st_words, d + o_status, 64, hipMemcpyDeviceToHost);
+  if (e == hipSuccess) e = hipMemcpy(&lf_end, d + o_end, 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) throw HipError(std::string("single-group LF pre-pass: ") + hipGetErrorString(e));
+  if (st_words[0]) throw ParseError(DecoderStatus_DecodeError, "GPU decode failed in the LF group of a single-group frame (corrupt bitstream)");
+  f.hf_start_bits = ParseHfGlobalAt(f, lf_end);
 }
 
 void JxlHipDecoder::CopyPlaneTap(int stage) {

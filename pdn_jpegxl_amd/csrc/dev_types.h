@@ -142,7 +142,8 @@ struct DevImage {
   float* stage_in[5][3];
   float* stage_out[5][3];
   int32_t stage_on[5];
-  int32_t final_stage;      // last enabled filter stage (0..3) converts to u8; 4 = no filter, out_only_kernel converts
+  int32_t final_stage;      // last enabled filter stage (0..3) converts to u8; 4 = no filter, out_only_kernel converts; 5 = fused kernel
+  int32_t fused_gab_epf1;   // Gaborish + one EPF iteration run as one kernel (filter_gab_epf1_kernel)
   uint32_t* tile_list;      // 64x64 tiles left to the generic reconstruction kernels (count in status[1])
   uint8_t* alpha;           // w*h
   uint8_t* out;             // w*h*nch_out interleaved

@@ -1196,9 +1196,9 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
     if (!f.has_global_tree) Fail("Modular frames without a global MA tree are not supported on the GPU path yet");
     return;   // nothing else is global in a Modular frame: every group section is decoded on the GPU
   }
-  // HfGlobal of a single-section frame starts where the GPU finishes the LF group (ParseHfGlobalAt); the two-phase
-  // submission that needs is not wired into the batch pipeline yet, so say so instead of decoding garbage.
-  if (f.single) Fail("single-group frames (<= 256x256) are not decoded on the GPU path yet");
+  // HfGlobal of a single-section frame starts where the GPU finishes the LF group: the decoder runs the LF stage of such
+  // frames first (JxlHipDecoder::PrepassSingle) and then calls ParseHfGlobalAt().
+  if (f.single) return;
   {
     Bits s(f.cs + f.sec_off[1 + f.nlf], f.sec_size[1 + f.nlf]);
     std::vector<float> custom[kNumQuantTables];

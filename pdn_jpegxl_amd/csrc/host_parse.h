@@ -104,6 +104,7 @@ struct ParsedFrame {
   uint64_t mod_data_bits = 0;                 // codestream bit position of the GlobalModular channel data (stream 0)
   bool single = false;                 // one TOC entry: all sections share one bit stream (frames that fit one group)
   uint64_t after_lf_global_bits = 0;   // codestream bit position right after the host-parsed part of LfGlobal
+  uint64_t hf_start_bits = 0;          // single-section frames: bit position right after HfGlobal (set by the LF pre-pass)
   // ---- HfGlobal
   bool dq_default = true;
   uint32_t num_presets = 1;

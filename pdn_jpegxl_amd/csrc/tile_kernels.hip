@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
   uint32_t* rq = ci + 64;                      // 64
   float* lft = (float*)(rq + 64);              // 64   LF samples of the tile / horizontally transformed
   float* Bs = lft + 64;                        // 85   small DCT bases, c = 1,2,4,8 at offsets (c*c-1)/3
-  float* cscale = Bs + 96;                     // 64   per cell: inv_global_scale / raw quant of its varblock
+  float* B816 = Bs + 96;                       // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
+  float* cscale = B816 + 320;                  // 64   per cell: inv_global_scale / raw quant of its varblock
   const float** cw = (const float**)(cscale + 64);   // 64   per cell: dequant table base
   uint32_t* cnq = (uint32_t*)(cw + 64);        // 64   per cell: entries per channel in that table
   const DevImage& im = imgs[blockIdx.y];
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
     Bl = Bl_lds;
   }
   if (tid < 85) Bs[tid] = basis_small[tid];
+  for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
   if (tid < 64) {
     const uint32_t info = ci[tid];
     const uint32_t q = t_quant_table[info & 0xFF];
@@ -220,17 +222,27 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
       if (info >> 31) {
         const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
         const int R = 8 << lcy;
-        const float* B = Bl + (R * R - 64) / 3 + iy * 8;
         const float* in = cfc + (cr - iy) * 8 * kLP + x;
         float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < R; k++) {
-          const float v0 = in[k * kLP], v1 = in[k * kLP + 1];
-          const float4 b0 = *(const float4*)(B + k * R);
-          const float4 b1 = *(const float4*)(B + k * R + 4);
-          a0[0] += v0 * b0.x; a0[1] += v0 * b0.y; a0[2] += v0 * b0.z; a0[3] += v0 * b0.w;
-          a0[4] += v0 * b1.x; a0[5] += v0 * b1.y; a0[6] += v0 * b1.z; a0[7] += v0 * b1.w;
-          a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;
-          a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;
+#define JXL_IDCT_STEP(Bp, v0, v1)                                                                  \
+  {                                                                                                \
+    const float4 b0 = *(const float4*)(Bp);                                                        \
+    const float4 b1 = *(const float4*)((Bp) + 4);                                                  \
+    a0[0] += v0 * b0.x; a0[1] += v0 * b0.y; a0[2] += v0 * b0.z; a0[3] += v0 * b0.w;                \
+    a0[4] += v0 * b1.x; a0[5] += v0 * b1.y; a0[6] += v0 * b1.z; a0[7] += v0 * b1.w;                \
+    a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;                \
+    a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;                \
+  }
+        if (R == 8) {            // the common sizes read their basis from LDS: no global load inside the pass
+#pragma unroll 2
+          for (int k = 0; k < 8; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
+        } else if (R == 16) {
+          const float* B = B816 + 64 + iy * 8;
+#pragma unroll 2
+          for (int k = 0; k < 16; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
+        } else {
+          const float* B = Bl + (R * R - 64) / 3 + iy * 8;
+          for (int k = 0; k < R; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * R, v0, v1) }
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) { tmpb[(cr * 8 + j) * kLP + x] = a0[j]; tmpb[(cr * 8 + j) * kLP + x + 1] = a1[j]; }
@@ -244,17 +256,18 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
       if (info >> 31) {
         const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
         const int C = 8 << lcx;
-        const float* B = Bl + (C * C - 64) / 3 + ix * 8;
         const float* in = tmpb + y * kLP + (cc - ix) * 8;
         float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < C; k++) {
-          const float v0 = in[k], v1 = in[k + kLP];
-          const float4 b0 = *(const float4*)(B + k * C);
-          const float4 b1 = *(const float4*)(B + k * C + 4);
-          a0[0] += v0 * b0.x; a0[1] += v0 * b0.y; a0[2] += v0 * b0.z; a0[3] += v0 * b0.w;
-          a0[4] += v0 * b1.x; a0[5] += v0 * b1.y; a0[6] += v0 * b1.z; a0[7] += v0 * b1.w;
-          a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;
-          a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;
+        if (C == 8) {
+#pragma unroll 2
+          for (int k = 0; k < 8; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
+        } else if (C == 16) {
+          const float* B = B816 + 64 + ix * 8;
+#pragma unroll 2
+          for (int k = 0; k < 16; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
+        } else {
+          const float* B = Bl + (C * C - 64) / 3 + ix * 8;
+          for (int k = 0; k < C; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * C, v0, v1) }
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) { cfc[y * kLP + cc * 8 + j] = a0[j]; cfc[(y + 1) * kLP + cc * 8 + j] = a1[j]; }
@@ -372,6 +385,89 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
   }
 }
 
+// Gaborish + EPF pass 1 (the only pass of epf_iters == 1) + XYB -> sRGB u8 in one kernel.  Tile = 32 x 32 output pixels:
+// XYB with a 3-pixel halo is staged in LDS, the Gaborish result (2-pixel halo, what the EPF reads) is written to a second LDS
+// tile, the EPF runs from there.  Out-of-frame positions are filled through the mirrored input, which gives the mirrored
+// Gaborish value because the 3x3 kernel is symmetric.  Saves one 24 B/px round trip through HBM and one launch.
+__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs) {
+  constexpr int TW = 32, TH = 32, HI = 3, HG = 2;
+  constexpr int IW = TW + 2 * HI, IH = TH + 2 * HI, GW = TW + 2 * HG, GH = TH + 2 * HG;
+  __shared__ float s_in[3][IH][IW + 1];
+  __shared__ float t[3][GH][GW + 1];
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.fused_gab_epf1) return;
+  const int w = im.w, h = im.h, wp = im.wp;
+  const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int x0 = tx * TW, y0 = ty * TH;
+  if (y0 + TH <= im.band_y0 || y0 >= im.band_y1) return;
+  const float* in0 = im.stage_in[0][0];
+  const float* in1 = im.stage_in[0][1];
+  const float* in2 = im.stage_in[0][2];
+  constexpr int kLoadIters = (IW * IH + 255) / 256;
+#pragma unroll
+  for (int it = 0; it < kLoadIters; it++) {
+    const int e0 = threadIdx.x + it * 256;
+    const int e = e0 < IW * IH ? e0 : IW * IH - 1;
+    const int ly = e / IW, lx = e % IW;
+    const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
+    const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
+    s_in[0][ly][lx] = v0;
+    s_in[1][ly][lx] = v1;
+    s_in[2][ly][lx] = v2;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < GW * GH; e += 256) {
+    const int gy = e / GW, gx = e % GW;
+    const int cy = gy + 1, cx = gx + 1;   // same position in the input tile (halo 3 vs 2)
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      t[c][gy][gx] = s_in[c][cy][cx] * im.gab_w[c][0] +
+                     (s_in[c][cy - 1][cx] + s_in[c][cy + 1][cx] + s_in[c][cy][cx - 1] + s_in[c][cy][cx + 1]) * im.gab_w[c][1] +
+                     (s_in[c][cy - 1][cx - 1] + s_in[c][cy - 1][cx + 1] + s_in[c][cy + 1][cx - 1] + s_in[c][cy + 1][cx + 1]) * im.gab_w[c][2];
+    }
+  }
+  __syncthreads();
+  const int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
+  const int plus[5][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}};
+#pragma unroll 2
+  for (int e = threadIdx.x; e < TW * TH; e += 256) {
+    const int ly = e / TW, lx = e % TW;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= w || y < im.band_y0 || y >= im.band_y1) continue;
+    const int cy = ly + HG, cx = lx + HG;
+    const float is = im.inv_sigma[(size_t)(y >> 3) * im.w8 + (x >> 3)];
+    float o0 = t[0][cy][cx], o1 = t[1][cy][cx], o2 = t[2][cy][cx];
+    if (!(is < -3.90524291751269967465540850526868f)) {
+      const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
+      const float inv = is * (border ? im.epf_border_sad_mul : 1.0f);
+      float wsum = 1.0f;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int dy = off1[k][0], dx = off1[k][1];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 5; p++) {
+          const int ay = cy + plus[p][0], ax = cx + plus[p][1];
+          s0 += fabsf(t[0][ay][ax] - t[0][ay + dy][ax + dx]);
+          s1 += fabsf(t[1][ay][ax] - t[1][ay + dy][ax + dx]);
+          s2 += fabsf(t[2][ay][ax] - t[2][ay + dy][ax + dx]);
+        }
+        const float sad = s0 * im.epf_channel_scale[0] + s1 * im.epf_channel_scale[1] + s2 * im.epf_channel_scale[2];
+        const float wt = fmaxf(0.0f, 1.0f + sad * inv);
+        wsum += wt;
+        o0 += wt * t[0][cy + dy][cx + dx];
+        o1 += wt * t[1][cy + dy][cx + dx];
+        o2 += wt * t[2][cy + dy][cx + dx];
+      }
+      const float iw = 1.0f / wsum;
+      o0 *= iw; o1 *= iw; o2 *= iw;
+    }
+    WritePixel(im, x, y, o0, o1, o2);
+  }
+}
+
 // no loop filter at all: plain conversion
 __global__ void out_only_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
@@ -388,7 +484,7 @@ __global__ void out_only_kernel(const DevImage* imgs) {
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, hipStream_t s) {
   static const bool basis_lds = getenv("JXLHIP_RECON_BASIS_LDS") != nullptr;
-  const size_t extra = (128 + 64 + 96 + 64 + 128 + 64) * 4;
+  const size_t extra = (128 + 64 + 96 + 320 + 64 + 128 + 64) * 4;
   if (basis_lds) {
     const size_t lds = (size_t)(2 * kTS * kLP + kBasisFloats) * 4 + extra;
     static bool raised = false;
@@ -405,9 +501,10 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
-                       hipStream_t s) {
+                       bool any_fused, hipStream_t s) {
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
+  if (any_fused) hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs);
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 1) hipLaunchKernelGGL(filter_tile_kernel<2>, g, dim3(256), 0, s, imgs);

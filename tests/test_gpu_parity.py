@@ -182,3 +182,21 @@ def test_band_decode_equals_whole_frame(oracle, gpu_decoder, distance, world):
         assert (got == whole[y0:y1]).all(), (rank, y0, y1)
         rows += y1 - y0
     assert rows == img.shape[0]
+
+
+# ---------------------------------------------------------------- frames that fit one group (one TOC entry, one bit stream)
+@pytest.mark.parametrize("size,kw", [((64, 48), {}), ((256, 256), {}), ((200, 120), dict(distance=3.0)), ((33, 250), dict(strategy_mode=2, seed=5)),
+                                     ((8, 8), {}), ((1, 1), {})])
+@pytest.mark.parametrize("layout", ["rgba", "rgb", "gray"])
+def test_single_group_frames(oracle, size, kw, layout):
+    w, h = size
+    img = synth(w, h, 41)
+    src = np.ascontiguousarray({"rgba": img, "rgb": img[..., :3], "gray": img[..., 1:2]}[layout])
+    data = oracle.encode(src, **kw)
+    ref = oracle.decode(data).pixels
+    got = api.load_image(data)
+    assert got.pixels.shape == ref.shape
+    d = np.abs(got.pixels.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() <= 0.01
+    if layout == "rgba":
+        assert (got.pixels[..., 3] == img[..., 3]).all()

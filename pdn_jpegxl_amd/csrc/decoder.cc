@@ -334,10 +334,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
-    size_t mod_plane[4], mod_desc, wp_lf, wp_grp, lf_end;
+    std::vector<size_t> mod_planes;
+    size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
-  std::vector<PerImg> L(n);
+  std::vector<PerImg> L((size_t)n);
   int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
@@ -355,11 +356,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       const bool resident_m = dev_data && dev_data[i] && f.cs_contiguous;
       l.cs = resident_m ? 0 : blob.Take(f.cs_size + 16);
       l.z_status = ws_zero.Take(64);
-      const int nch = f.ncolor + (f.alpha_index >= 0 ? 1 : 0);
-      for (int c = 0; c < nch; c++) l.mod_plane[c] = ws.Take(4 * (size_t)f.xsize * f.ysize);
-      l.mod_desc = ws.Take((size_t)f.ng * 4 * sizeof(ChanDesc));
-      if (f.tree_uses_wp) l.wp_grp = ws.Take((size_t)f.ng * 10 * (f.group_dim + 2) * 4);
-      n_mod_tasks += ((int)f.ng + 63) / 64;
+      for (auto& pl : f.mod_planes) l.mod_planes.push_back(ws.Take(4 * (size_t)std::max(1, pl.w) * std::max(1, pl.h)));
+      const size_t nsec = 1 + (size_t)f.nlf + f.ng;
+      l.mod_chan = blob.Take(sizeof(ModChanDev) * f.mod_coded.size());
+      l.mod_desc = ws.Take(nsec * f.mod_coded.size() * sizeof(ChanDesc));
+      if (f.tree_uses_wp) l.wp_grp = ws.Take(nsec * 10 * (f.group_dim + 2) * 4);
+      n_mod_tasks += f.single ? 1 : ((int)nsec + 63) / 64;
       continue;
     }
     l.a_cmap = blob.Take(f.acode.ctx_map.size());
@@ -463,6 +465,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   SectionTask* mod_tasks = (SectionTask*)(h_blob + off_mod_tasks);
   int nlf_t = 0, npass_t = 0, nalpha_t = 0, nlf_ans_t = 0, nmod_t = 0, max_groups = 1, max_mod_groups = 1;
   size_t lds_mod = 0, max_mod_pixels = 1;
+  int max_mod_coded = 1;
+  struct ModLaunch { int kind; int32_t *a, *b, *c; int aw, ah, rw, rh, type; };
+  std::vector<ModLaunch> mod_ops;
   uint8_t* wz = d_ws;
   uint8_t* wr = d_ws + zero_bytes;
   for (int i = 0; i < n; i++) {
@@ -520,19 +525,39 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.group_dim = (int32_t)f.group_dim;
       d.single = f.single ? 1 : 0;
       d.mod_data_bits = f.mod_data_bits;
-      d.mod_ntr = (int32_t)std::min<size_t>(4, f.mod_transforms.size());
+      // without Squeeze (at most four colour transforms) the RCTs are undone inside modular_out_kernel; otherwise every inverse
+      // operation is its own launch (below) and the output kernel only clamps and interleaves
+      const bool inline_rct = !f.mod_has_squeeze && f.mod_transforms.size() <= 4;
+      d.mod_ntr = inline_rct ? (int32_t)f.mod_transforms.size() : 0;
       for (int t = 0; t < d.mod_ntr; t++) { d.mod_tr[t][0] = (int32_t)f.mod_transforms[t].begin_c; d.mod_tr[t][1] = (int32_t)f.mod_transforms[t].rct_type; }
-      for (int c = 0; c < d.mod_nch; c++) d.mod_plane[c] = (int32_t*)(wr + l.mod_plane[c]);
+      for (int c = 0; c < d.mod_nch; c++) d.mod_plane[c] = (int32_t*)(wr + l.mod_planes[c]);
+      {
+        std::vector<ModChanDev> table;
+        for (auto& ch : f.mod_coded) table.push_back(ModChanDev{ch.w, ch.h, ch.hshift, ch.vshift, (int32_t*)(wr + l.mod_planes[ch.plane])});
+        put(l.mod_chan, table.data(), sizeof(ModChanDev) * table.size());
+      }
+      d.mod_chan = (const ModChanDev*)(d_blob + l.mod_chan);
+      d.mod_ncoded = (int32_t)f.mod_coded.size();
+      d.mod_first_group = (int32_t)f.mod_first_group_channel;
       d.mod_desc = (ChanDesc*)(wr + l.mod_desc);
       if (f.tree_uses_wp) { d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * ((int64_t)f.group_dim + 2); }
+      if (!inline_rct)
+        for (auto& op : f.mod_ops) {
+          const ParsedFrame::ModPlane &pa = f.mod_planes[op.a], &pb = f.mod_planes[op.b];
+          mod_ops.push_back(ModLaunch{op.kind, (int32_t*)(wr + l.mod_planes[op.a]), (int32_t*)(wr + l.mod_planes[op.b]),
+                                      (int32_t*)(wr + l.mod_planes[op.c]), pa.w, pa.h, pb.w, pb.h, op.type});
+        }
       d.status = (uint32_t*)(wz + l.z_status);
       status_off[i] = l.z_status;
       d.out = dev_out[i];
       auto code_lds_m = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
       lds_mod = std::max(lds_mod, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
-      max_mod_groups = std::max<int>(max_mod_groups, (int)f.ng);
+      const uint32_t nsec = 1 + f.nlf + f.ng;
+      max_mod_groups = std::max<int>(max_mod_groups, (int)nsec);
+      max_mod_coded = std::max<int>(max_mod_coded, (int)f.mod_coded.size());
       max_mod_pixels = std::max(max_mod_pixels, (size_t)f.xsize * f.ysize);
-      for (uint32_t g = 0; g < f.ng; g += 64) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, f.ng - g), 0};
+      if (f.single) mod_tasks[nmod_t++] = SectionTask{i, 0, 1, 0};   // one bit stream: one lane walks all three sections
+      else for (uint32_t g = 0; g < nsec; g += 64) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, nsec - g), 0};
       continue;
     }
     code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
@@ -692,8 +717,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
-    LaunchModular(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
-                  max_mod_pixels, stream);
+    LaunchModularAns(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
+                     max_mod_coded, stream);
+    for (auto& op : mod_ops) LaunchModularOp(op.kind, op.a, op.b, op.c, op.aw, op.ah, op.rw, op.rh, op.type, stream);
+    LaunchModularOut(d_imgs, n, max_mod_pixels, stream);
     Mark("modular", stream, 2);
   }
   for (int i = 0; i < n; i++)

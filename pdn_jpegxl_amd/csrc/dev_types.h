@@ -54,6 +54,12 @@ struct ChanDesc {
   int32_t pad0, pad1;
 };
 
+// One coded channel of a Modular frame (sizes after Squeeze; shifts tell which sections code it).
+struct ModChanDev {
+  int32_t w, h, hshift, vshift;
+  int32_t* plane;
+};
+
 struct DevImage {
   // geometry
   int32_t w, h, w8, h8, wp, hp, wt, ht;
@@ -124,10 +130,12 @@ struct DevImage {
   // Modular frames (lossless): up to 4 channels of the whole image, decoded per group (or, for a frame that fits one
   // group, from the GlobalModular stream), then inverse colour transforms and interleaving in modular_out_kernel
   int32_t is_modular, mod_nch, group_dim, mod_ntr;
-  int32_t mod_tr[4][2];     // reversible colour transforms in stream order: begin channel, type
-  int32_t* mod_plane[4];    // w*h each
-  ChanDesc* mod_desc;       // per group: 4 entries
-  uint64_t mod_data_bits;   // single-group frames: bit position of the channel data inside LfGlobal
+  int32_t mod_tr[4][2];     // reversible colour transforms in stream order: begin channel, type (frames without Squeeze: undone in modular_out)
+  int32_t* mod_plane[4];    // the image channels, w*h each
+  const ModChanDev* mod_chan;   // coded channels (after the transforms), mod_ncoded entries
+  int32_t mod_ncoded, mod_first_group;   // channels before mod_first_group are coded in the GlobalModular stream
+  ChanDesc* mod_desc;       // [section][coded channel]; sections: 0 global, 1 + g LF group g, 1 + nlf + g pass group g
+  uint64_t mod_data_bits;   // bit position of the GlobalModular channel data inside LfGlobal
   // weighted-predictor state (only allocated when the MA tree references it): lane-private scratch per LF group / per group
   int32_t* wp_lf;           // [nlf][kWpLfInts]
   int32_t* wp_grp;          // [ng][wp_grp_ints]

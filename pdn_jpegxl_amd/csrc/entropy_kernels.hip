@@ -616,14 +616,75 @@ __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_ge
   }
 }
 
+// The same recurrence with all global traffic coalesced: the channel rectangle is walked in 64-row batches x 64-column
+// blocks; a block is loaded into an LDS tile row by row (lanes along x), the skewed pass runs inside the tile, and the
+// results leave it row by row again.  (Reading 64 different rows per step straight from HBM costs a cache line per
+// 4-byte sample once thousands of wavefronts run: measured 404 MB of traffic per 4K alpha plane instead of 41 MB.)
+// W / N / NW live in registers and simply carry over from block to block.  tile: 64 x 65 ints of LDS.
+template <bool kU8Out>
+__device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
+                                 uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, JXL_LDS int32_t* tile, int lane) {
+  JXL_GLB int32_t* const plane = G(plane_generic);
+  JXL_GLB uint8_t* const out8 = G(out8_generic);
+  for (int y0 = 0; y0 < h; y0 += 64) {
+    const int nrows = min(64, h - y0);
+    const int y = y0 + lane;
+    const bool row_active = lane < nrows;
+    uint32_t pred = 0;
+    if (row_active) { bool u = false; pred = RowNode(tree, chan, sid, y, &u).a & 0xFF; }
+    const bool more = y0 + 64 < h;
+    int32_t W = 0, N = 0, NW = 0, val = 0;
+    for (int x0 = 0; x0 < w; x0 += 64) {
+      const int ncols = min(64, w - x0);
+      if (kind == kChanResid && lane < ncols)
+        for (int r = 0; r < nrows; r++) tile[r * 65 + lane] = plane[(size_t)(y0 + r) * stride + x0 + lane];
+      __syncthreads();
+      const int steps = ncols + nrows - 1;
+      for (int t = 0; t < steps; t++) {
+        const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
+        const int c = t - lane;
+        if (row_active && c >= 0 && c < ncols) {
+          const int x = x0 + c;
+          const int32_t r = kind == kChanResid ? tile[lane * 65 + c] : cvalue;
+          const int32_t n_in = lane == 0 ? (y ? carry[x] : 0) : from_up;
+          if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
+          else if (y) { NW = N; N = n_in; }
+          else { NW = W; N = W; }
+          uint32_t guess;
+          if (pred == 0) guess = 0;
+          else if (pred == 1) guess = (uint32_t)W;
+          else if (pred == 2) guess = (uint32_t)N;
+          else {
+            const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
+            guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
+          }
+          val = (int32_t)((uint32_t)r + guess);
+          tile[lane * 65 + c] = val;
+          if (more && lane == nrows - 1) carry[x] = val;
+          W = val;
+        }
+      }
+      __syncthreads();
+      if (lane < ncols)
+        for (int r = 0; r < nrows; r++) {
+          const int32_t v = tile[r * 65 + lane];
+          if (kU8Out) out8[(size_t)(y0 + r) * out_stride + x0 + lane] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+          else plane[(size_t)(y0 + r) * stride + x0 + lane] = v;
+        }
+      __syncthreads();
+    }
+  }
+}
+
 // Applies a channel descriptor to an int32 plane (phase B for planes that stay int32).
 __device__ void FinishChannelI32(const ChanDesc d, const I4* tree, int chan, int sid, int32_t* plane, int stride, int w, int h,
-                                 JXL_LDS int32_t* carry, int lane) {
+                                 JXL_LDS int32_t* carry, int lane, JXL_LDS int32_t* tile = nullptr) {
   if (w <= 0 || h <= 0) return;
   if (d.kind == kChanConst) {
     for (int i = lane; i < w * h; i += 64) plane[(size_t)(i / w) * stride + (i % w)] = d.value;
   } else if (d.kind == kChanResid) {
-    PredictWave<false>(tree, chan, sid, plane, stride, w, h, d.kind, d.value, nullptr, 0, carry, lane);
+    if (tile) PredictWaveTiled<false>(tree, chan, sid, plane, stride, w, h, d.kind, d.value, nullptr, 0, carry, tile, lane);
+    else PredictWave<false>(tree, chan, sid, plane, stride, w, h, d.kind, d.value, nullptr, 0, carry, lane);
   }
 }
 
@@ -1101,6 +1162,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
 // Phase B: one wavefront per group: predictors (or plain conversion) -> 8-bit alpha plane.
 __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) {
   __shared__ int32_t s_carry[256];
+  __shared__ int32_t s_tile[64 * 65];
   const DevImage& im = imgs[blockIdx.y];
   const int g = blockIdx.x;
   if (!im.has_alpha || g >= im.ng || im.is_modular) return;
@@ -1114,7 +1176,8 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
   const int sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
   if (d.kind == kChanResid) {
-    PredictWave<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry, lane);
+    PredictWaveTiled<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry,
+                           (JXL_LDS int32_t*)s_tile, lane);
   } else {
     const bool cst = d.kind == kChanConst;
     for (int i = lane; i < gw * gh; i += 64) {
@@ -1126,7 +1189,34 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
 }
 
 // ------------------------------------------------------------------ Modular (lossless) frames
-// Phase A: one lane per group; every channel of the group's rectangle is one Modular channel of the group's stream.
+// Sections of a Modular frame: 0 = GlobalModular stream (channels before mod_first_group), 1 + g = LF group g (channels
+// squeezed by >= 3 in both directions), 1 + nlf + g = pass group g (the rest).  A section codes, for each of its channels, the
+// rectangle of that channel covered by the group; the channel index property counts the channels the section holds.
+struct ModRect { int x0, y0, w, h; };
+__device__ __forceinline__ bool ModSectionRect(const DevImage& im, int kind, int g, const ModChanDev& ch, int c, ModRect* r) {
+  if (kind == 0) {
+    if (c >= im.mod_first_group) return false;
+    r->x0 = 0; r->y0 = 0; r->w = ch.w; r->h = ch.h;
+    return ch.w > 0 && ch.h > 0;
+  }
+  if (c < im.mod_first_group) return false;
+  const int shift = min(ch.hshift, ch.vshift);
+  if (kind == 1 ? shift < 3 : shift > 2) return false;
+  const int dim = kind == 1 ? im.group_dim * 8 : im.group_dim;
+  const int gx = kind == 1 ? g % im.xlf : g % im.xg, gy = kind == 1 ? g / im.xlf : g / im.xg;
+  const int x0 = (gx * dim) >> ch.hshift, y0 = (gy * dim) >> ch.vshift;
+  const int w = max(0, min(dim >> ch.hshift, ch.w - x0)), h = max(0, min(dim >> ch.vshift, ch.h - y0));
+  r->x0 = x0; r->y0 = y0; r->w = w; r->h = h;
+  return w > 0 && h > 0;
+}
+__device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kind, int* g, int* sid, int* sec) {
+  if (s == 0) { *kind = 0; *g = 0; *sid = 0; *sec = 0; }
+  else if (s <= im.nlf) { *kind = 1; *g = s - 1; *sid = 1 + im.nlf + *g; *sec = 1 + *g; }
+  else { *kind = 2; *g = s - 1 - im.nlf; *sid = 1 + 3 * im.nlf + kNumQuantTables + *g; *sec = 2 + im.nlf + *g; }
+}
+
+// Phase A: one lane per section.  A frame with a single TOC entry is one bit stream: its lane walks global, LF group and pass
+// group one after the other.
 template <bool kLds>
 __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks) {
   extern __shared__ __align__(16) uint8_t smem[];
@@ -1136,50 +1226,142 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
   LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
   const int lane = threadIdx.x;
   if (lane >= task.count) return;
-  const int g = task.first + lane;
-  const int gd = im.group_dim;
-  const int gx = g % im.xg, gy = g / im.xg;
-  const int x0 = gx * gd, y0 = gy * gd;
-  const int gw = min(gd, im.w - x0), gh = min(gd, im.h - y0);
-  ChanDesc* desc = im.mod_desc + (size_t)g * 4;
-  // a frame that fits one group codes its channels in the GlobalModular stream (id 0) right after the header in LfGlobal
-  const int sec = im.single ? 0 : 2 + im.nlf + g;
-  const uint64_t start = im.single ? im.mod_data_bits : im.sec_off[sec] * 8;
-  const int sid = im.single ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  const int s0 = task.first + lane;
+  const int nsub = im.single ? 3 : 1;   // single: this lane continues through sections 0, 1, 2
   LaneBits b;
-  b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
+  b.rs = 0;   // not initialised yet
   uint32_t err = 0;
-  if (!im.single && b.Read(4) != 3) err |= kErrUnsupportedHeader;
-  if (!err) {
+  int32_t* const wps = im.wp_grp ? im.wp_grp + (size_t)s0 * im.wp_grp_ints : nullptr;
+  for (int k = 0; k < nsub && !err; k++) {
+    const int s = s0 + k;
+    int kind, g, sid, sec;
+    ModSectionOf(im, s, &kind, &g, &sid, &sec);
+    if (im.single) sec = 0;
+    ChanDesc* desc = im.mod_desc + (size_t)s * im.mod_ncoded;
+    // does the section hold any channel?  (an empty one has no bits at all, not even a header)
+    bool any = false;
+    for (int c = 0; c < im.mod_ncoded && !any; c++) { ModRect r; any = ModSectionRect(im, kind, g, im.mod_chan[c], c, &r); }
+    if (!any) continue;
+    uint64_t start = 0;
+    if (kind == 0) { start = im.mod_data_bits; b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64); }
+    else if (!im.single) {
+      if (im.sec_size[sec] == 0) { err |= kErrBitstream; break; }
+      start = im.sec_off[sec] * 8;
+      b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
+    } else if (k > 0 && b.rs == 0) {   // single stream but the global part was empty: start where LfGlobal's header ended
+      b.Init(im.cs, im.cs_size, im.mod_data_bits, (JXL_LDS uint32_t*)smem + lane, 64);
+    }
+    if (kind != 0 && b.Read(4) != 3) { err |= kErrUnsupportedHeader; break; }
     uint32_t state = b.Read(32);
+    int sub = 0;
 #pragma unroll 1
-    for (int c = 0; c < im.mod_nch; c++)
-      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, c, sid, gw, gh, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, desc + c,
-                              im.wp_grp ? im.wp_grp + (size_t)g * im.wp_grp_ints : nullptr);
-    if (state != 0x130000u || start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
+    for (int c = 0; c < im.mod_ncoded; c++) {
+      const ModChanDev ch = im.mod_chan[c];
+      ModRect r;
+      if (!ModSectionRect(im, kind, g, ch, c, &r)) continue;
+      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, sub, sid, r.w, r.h, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, desc + c, wps);
+      sub++;
+    }
+    if (state != 0x130000u) err |= kErrBitstream;
+    if (!im.single && start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
   if (err) {
     ChanDesc d;
     d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
-    for (int c = 0; c < 4; c++) desc[c] = d;
+    for (int k = 0; k < nsub; k++)
+      for (int c = 0; c < im.mod_ncoded; c++) im.mod_desc[(size_t)(s0 + k) * im.mod_ncoded + c] = d;
     SetError(im, err);
   }
 }
 
-// Phase B: one wavefront per (group, channel)
-__global__ __launch_bounds__(64) void modular_finish_kernel(const DevImage* imgs) {
+// Phase B: one wavefront per (section, coded channel)
+__global__ __launch_bounds__(64) void modular_finish_kernel(const DevImage* imgs, int max_coded) {
   __shared__ int32_t s_carry[kCarryInts];
+  __shared__ int32_t s_tile[64 * 65];
   const DevImage& im = imgs[blockIdx.y];
   if (!im.is_modular) return;
-  const int g = blockIdx.x >> 2, c = blockIdx.x & 3;
-  if (g >= im.ng || c >= im.mod_nch) return;
-  const int gd = im.group_dim;
-  const int gx = g % im.xg, gy = g / im.xg;
-  const int x0 = gx * gd, y0 = gy * gd;
-  const int gw = min(gd, im.w - x0), gh = min(gd, im.h - y0);
-  const int sid = im.single ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
-  FinishChannelI32(im.mod_desc[(size_t)g * 4 + c], (const I4*)im.tree, c, sid, im.mod_plane[c] + (size_t)y0 * im.w + x0, im.w, gw, gh,
-                   (JXL_LDS int32_t*)s_carry, threadIdx.x);
+  const int s = blockIdx.x / max_coded, c = blockIdx.x % max_coded;
+  if (s >= 1 + im.nlf + im.ng || c >= im.mod_ncoded) return;
+  int kind, g, sid, sec;
+  ModSectionOf(im, s, &kind, &g, &sid, &sec);
+  const ModChanDev ch = im.mod_chan[c];
+  ModRect r;
+  if (!ModSectionRect(im, kind, g, ch, c, &r)) return;
+  // the channel-index property of the section: how many of its channels precede this one
+  int sub = 0;
+  for (int k = 0; k < c; k++) { ModRect rk; sub += ModSectionRect(im, kind, g, im.mod_chan[k], k, &rk) ? 1 : 0; }
+  FinishChannelI32(im.mod_desc[(size_t)s * im.mod_ncoded + c], (const I4*)im.tree, sub, sid, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, r.w, r.h,
+                   (JXL_LDS int32_t*)s_carry, threadIdx.x, (JXL_LDS int32_t*)s_tile);
+}
+
+// Inverse Squeeze steps (between phase B and the output): the average / residual pair of one step -> the unsqueezed channel.
+__device__ __forceinline__ int64_t SmoothTendency(int64_t B, int64_t a, int64_t n) {
+  int64_t diff = 0;
+  if (B >= a && a >= n) {
+    diff = (4 * B - 3 * n - a + 6) / 12;
+    if (diff - (diff & 1) > 2 * (B - a)) diff = 2 * (B - a) + 1;
+    if (diff + (diff & 1) > 2 * (a - n)) diff = 2 * (a - n);
+  } else if (B <= a && a <= n) {
+    diff = (4 * B - 3 * n - a - 6) / 12;
+    if (diff + (diff & 1) < 2 * (B - a)) diff = 2 * (B - a) - 1;
+    if (diff - (diff & 1) < 2 * (a - n)) diff = 2 * (a - n);
+  }
+  return diff;
+}
+// horizontal: one thread per row (the recurrence runs along x)
+__global__ void unsqueeze_h_kernel(const int32_t* avg, const int32_t* res, int32_t* out, int aw, int ah, int rw) {
+  const int y = blockIdx.x * blockDim.x + threadIdx.x;
+  if (y >= ah) return;
+  const int32_t* pa = avg + (size_t)y * aw;
+  const int32_t* pr = res + (size_t)y * rw;
+  int32_t* po = out + (size_t)y * (aw + rw);
+  int64_t left = 0;
+  for (int x = 0; x < rw; x++) {
+    const int64_t a = pa[x], next = x + 1 < aw ? pa[x + 1] : a;
+    if (x == 0) left = a;
+    const int64_t diff = (int64_t)pr[x] + SmoothTendency(left, a, next);
+    const int64_t A = ((a * 2) + diff + (diff > 0 ? -(diff & 1) : (diff & 1))) >> 1;
+    po[2 * x] = (int32_t)A;
+    po[2 * x + 1] = (int32_t)(A - diff);
+    left = A - diff;
+  }
+  if (aw > rw) po[2 * rw] = pa[rw];
+}
+// vertical: one thread per column (the recurrence runs along y; coalesced across threads)
+__global__ void unsqueeze_v_kernel(const int32_t* avg, const int32_t* res, int32_t* out, int aw, int ah, int rh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= aw) return;
+  int64_t top = 0;
+  for (int y = 0; y < rh; y++) {
+    const int64_t a = avg[(size_t)y * aw + x], next = y + 1 < ah ? avg[(size_t)(y + 1) * aw + x] : a;
+    if (y == 0) top = a;
+    const int64_t diff = (int64_t)res[(size_t)y * aw + x] + SmoothTendency(top, a, next);
+    const int64_t A = ((a * 2) + diff + (diff > 0 ? -(diff & 1) : (diff & 1))) >> 1;
+    out[(size_t)(2 * y) * aw + x] = (int32_t)A;
+    out[(size_t)(2 * y + 1) * aw + x] = (int32_t)(A - diff);
+    top = A - diff;
+  }
+  if (ah > rh) out[(size_t)(2 * rh) * aw + x] = avg[(size_t)rh * aw + x];
+}
+// inverse reversible colour transform on three planes of n samples, in place
+__global__ void rct_inverse_kernel(int32_t* p0, int32_t* p1, int32_t* p2, size_t n, int type) {
+  const int perm = type / 7, custom = type % 7;
+  int32_t* dst[3] = {p0, p1, p2};
+  int32_t* da = dst[perm % 3];
+  int32_t* db = dst[(perm + 1 + perm / 3) % 3];
+  int32_t* dc = dst[(perm + 2 - perm / 3) % 3];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int32_t a = p0[i], b = p1[i], c = p2[i];
+    if (custom == 6) {
+      const int32_t tmp = a - (c >> 1), G = c + tmp, B = tmp - (b >> 1), R = B + b;
+      a = R; b = G; c = B;
+    } else {
+      if (custom & 1) c += a;
+      if ((custom >> 1) == 1) b += a;
+      else if ((custom >> 1) == 2) b += (a + c) >> 1;
+    }
+    da[i] = a; db[i] = b; dc[i] = c;
+  }
 }
 
 // Inverse reversible colour transforms (last first), clamp, interleave.
@@ -1262,8 +1444,8 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
   }
 }
 
-void LaunchModular(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_groups, size_t max_pixels,
-                   hipStream_t s) {
+void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
+                      hipStream_t s) {
   if (ntasks <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
@@ -1271,7 +1453,23 @@ void LaunchModular(const DevImage* imgs, int nimg, const SectionTask* tasks, int
   } else {
     hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), 64 * kRingWords * 4, s, imgs, tasks);
   }
-  hipLaunchKernelGGL(modular_finish_kernel, dim3(max_groups * 4, nimg), dim3(64), 0, s, imgs);
+  hipLaunchKernelGGL(modular_finish_kernel, dim3(max_sections * max_coded, nimg), dim3(64), 0, s, imgs, max_coded);
+}
+
+void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s) {
+  if (kind == 0) {
+    const size_t n = (size_t)aw * ah;
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (n) hipLaunchKernelGGL(rct_inverse_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a, b, c, n, type);
+  } else if (kind == 1) {
+    if (ah > 0 && aw > 0) hipLaunchKernelGGL(unsqueeze_h_kernel, dim3((ah + 63) / 64), dim3(64), 0, s, a, b, c, aw, ah, rw);
+  } else {
+    if (ah > 0 && aw > 0) hipLaunchKernelGGL(unsqueeze_v_kernel, dim3((aw + 63) / 64), dim3(64), 0, s, a, b, c, aw, ah, rh);
+  }
+}
+
+void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s) {
   size_t b = (max_pixels + 255) / 256;
   if (b > 8192) b = 8192;
   hipLaunchKernelGGL(modular_out_kernel, dim3((unsigned)b, nimg), dim3(256), 0, s, imgs);

@@ -754,12 +754,82 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
     for (uint32_t i = 0; i < ntr; i++) {
       ParsedFrame::ModTransform t;
       t.id = r.u(2);
-      REQUIRE(t.id == 0, t.id == 2 ? "Squeeze transforms are not decoded on the GPU path yet" : "Palette transforms are not decoded on the GPU path yet");
-      t.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
-      t.rct_type = r.U32(V(6), B(2), B(4, 2), B(6, 10));
-      REQUIRE(t.rct_type < 42 && t.begin_c + 3 <= nchan, "reversible colour transform out of range");
+      REQUIRE(t.id != 3, "invalid modular transform");
+      REQUIRE(t.id != 1, "Palette transforms are not decoded on the GPU path yet");
+      if (t.id == 0) {
+        t.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
+        t.rct_type = r.U32(V(6), B(2), B(4, 2), B(6, 10));
+        REQUIRE(t.rct_type < 42, "reversible colour transform type");
+      } else {
+        uint32_t nsq = r.U32(V(0), B(4, 1), B(6, 9), B(8, 41));
+        t.squeezes.resize(nsq);
+        for (auto& q : t.squeezes) {
+          q.horizontal = r.b();
+          q.in_place = r.b();
+          q.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
+          q.num_c = r.U32(V(1), V(2), V(3), B(4, 4));
+        }
+      }
       f.mod_transforms.push_back(t);
     }
+  }
+  if (f.encoding == 1) {
+    // simulate the transforms on the channel list (sizes only): what is coded, and how to get back
+    typedef ParsedFrame::ModChan Chan;
+    std::vector<Chan> cur;
+    for (size_t c = 0; c < nchan; c++) {
+      Chan ch;
+      ch.w = (int32_t)f.xsize; ch.h = (int32_t)f.ysize; ch.plane = (int32_t)c;
+      cur.push_back(ch);
+      f.mod_planes.push_back({ch.w, ch.h});
+    }
+    std::vector<ParsedFrame::ModOp> fwd;
+    for (auto& t : f.mod_transforms) {
+      if (t.id == 0) {
+        REQUIRE((size_t)t.begin_c + 3 <= cur.size(), "reversible colour transform out of range");
+        const Chan &a = cur[t.begin_c], &b2 = cur[t.begin_c + 1], &c2 = cur[t.begin_c + 2];
+        REQUIRE(a.w == b2.w && a.h == b2.h && a.w == c2.w && a.h == c2.h, "reversible colour transform on channels of different size");
+        fwd.push_back({0, a.plane, b2.plane, c2.plane, (int32_t)t.rct_type});
+        continue;
+      }
+      f.mod_has_squeeze = true;
+      std::vector<ParsedFrame::ModSqueeze> sq = t.squeezes;
+      if (sq.empty()) {   // default parameters: chroma first, then alternate until no side exceeds 8
+        const int nb = (int)cur.size();
+        int w = cur[0].w, h = cur[0].h;
+        if (nb > 2 && cur[1].w == w && cur[1].h == h) {
+          sq.push_back({true, false, 1, 2});
+          sq.push_back({false, false, 1, 2});
+        }
+        ParsedFrame::ModSqueeze p{true, true, 0, (uint32_t)nb};
+        if (h > w && h > 8) { p.horizontal = false; sq.push_back(p); h = (h + 1) / 2; }
+        while (w > 8 || h > 8) {
+          if (w > 8) { p.horizontal = true; sq.push_back(p); w = (w + 1) / 2; }
+          if (h > 8) { p.horizontal = false; sq.push_back(p); h = (h + 1) / 2; }
+        }
+      }
+      for (auto& q : sq) {
+        REQUIRE(q.num_c > 0 && (size_t)q.begin_c + q.num_c <= cur.size(), "squeeze channel range");
+        const uint32_t end_c = q.begin_c + q.num_c - 1;
+        const size_t offset = q.in_place ? end_c + 1 : cur.size();
+        for (uint32_t c = q.begin_c; c <= end_c; c++) {
+          Chan src = cur[c], avg = src, res = src;
+          if (q.horizontal) { avg.w = (src.w + 1) / 2; avg.hshift++; res.w = src.w - avg.w; res.hshift = avg.hshift; }
+          else { avg.h = (src.h + 1) / 2; avg.vshift++; res.h = src.h - avg.h; res.vshift = avg.vshift; }
+          avg.plane = (int32_t)f.mod_planes.size(); f.mod_planes.push_back({avg.w, avg.h});
+          res.plane = (int32_t)f.mod_planes.size(); f.mod_planes.push_back({res.w, res.h});
+          fwd.push_back({q.horizontal ? 1 : 2, avg.plane, res.plane, src.plane, 0});
+          cur[c] = avg;
+          cur.insert(cur.begin() + offset + (c - q.begin_c), res);
+          REQUIRE(cur.size() <= 4096 && f.mod_planes.size() <= 8192, "too many squeeze steps");
+        }
+      }
+    }
+    f.mod_coded = cur;
+    f.mod_ops.assign(fwd.rbegin(), fwd.rend());
+    uint32_t fg = 0;
+    for (; fg < cur.size(); fg++) if (cur[fg].w > (int32_t)f.group_dim || cur[fg].h > (int32_t)f.group_dim) break;
+    f.mod_first_group_channel = fg;
   }
   REQUIRE(r.ok(), "truncated LfGlobal");
 }

@@ -14,9 +14,12 @@ void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int
                     const uint16_t* natural_orders_small, hipStream_t s);
 void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
-// Modular (lossless) frames: per-group ANS phase, predictor phase, inverse colour transforms + interleave
-void LaunchModular(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_groups, size_t max_pixels,
-                   hipStream_t s);
+// Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical
+// unsqueeze of planes a (average), b (residual) into c); clamp + interleave
+void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
+                      hipStream_t s);
+void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
+void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,

@@ -39,7 +39,11 @@ def test_callback_failures_map_to_reference_statuses(oracle):
         assert e.value.status == status
 
 
-def test_unsupported_streams_fail_loudly(oracle):
+def test_broken_streams_fail_loudly(oracle):
+    data = oracle.encode(synth(300, 300, 4))
     with pytest.raises(api.FormatError) as e:
-        api.load_image(oracle.encode(synth(300, 300, 4), lossless=True, lossless_squeeze=True))
-    assert e.value.status == "DecodeError" and "Squeeze" in str(e.value)
+        api.load_image(data[: len(data) // 2])
+    assert e.value.status == "DecodeError" and str(e.value)
+    with pytest.raises(api.FormatError) as e:
+        api.load_image(b"not a jxl file at all")
+    assert e.value.status == "InvalidFileSignature"

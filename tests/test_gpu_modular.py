@@ -42,6 +42,20 @@ def test_weighted_predictor_streams_decode_bit_exact(oracle, size, layout):
         assert got.pixels.shape == src.shape and (got.pixels == src).all(), pred
 
 
+@pytest.mark.parametrize("size", [(300, 280), (200, 100), (777, 531), (64, 9), (2100, 300)])
+@pytest.mark.parametrize("layout", ["rgba", "rgb", "gray"])
+def test_squeeze_streams_decode_bit_exact(oracle, size, layout):
+    """Squeeze (default parameters: chroma first, then alternating horizontal / vertical steps down to 8 pixels) on top of the
+    colour transform: dozens of channels of every size, spread over the global stream, the LF groups and the pass groups."""
+    w, h = size
+    img = synth(w, h, 37)
+    src = np.ascontiguousarray({"rgba": img, "rgb": img[..., :3], "gray": img[..., 1:2]}[layout])
+    for kw in (dict(lossless_tree=1, lossless_predictor=5), dict()):   # plain gradient tree, and the weighted-predictor default
+        data = oracle.encode(src, lossless=True, lossless_squeeze=True, **kw)
+        got = api.load_image(data)
+        assert got.pixels.shape == src.shape and (got.pixels == src).all(), kw
+
+
 @pytest.mark.parametrize("predictor", [0, 1, 2, 3, 4, 7, 8, 9, 10, 11, 12, 13])
 def test_every_plain_predictor(oracle, predictor):
     img = synth(300, 260, 23)
@@ -76,6 +90,9 @@ def test_4k_lossless_bit_exact(oracle):
     assert got.pixels.shape == img.shape and (got.pixels == img).all()
     rgb = np.ascontiguousarray(img[..., :3])
     data = oracle.encode(rgb, lossless=True, lossless_tree=1, lossless_predictor=5)
+    assert (api.load_image(data).pixels == rgb).all()
+    # Squeeze + MA-tree (weighted) predictor, as BASELINE.json words the config
+    data = oracle.encode(rgb, lossless=True, lossless_squeeze=True)
     assert (api.load_image(data).pixels == rgb).all()
 
 

@@ -83,7 +83,9 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
   const float** cw = (const float**)(cscale + 64);   // 64   per cell: dequant table base
   uint32_t* cnq = (uint32_t*)(cw + 64);        // 64   per cell: entries per channel in that table
   const DevImage& im = imgs[blockIdx.y];
-  const int tile = blockIdx.x;
+  // One workgroup per (tile, channel): the kernel is bound by the latency of its barrier-separated phases, not by bandwidth,
+  // so three short workgroups in flight beat one that walks the channels (X and B re-read the Y coefficients for chroma from luma).
+  const int tile = blockIdx.x / 3, cidx_wg = blockIdx.x % 3;
   if (tile >= im.wt * im.ht) return;
   if (ablate & 16) return;
   const int tid = threadIdx.x;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
     }
   }
   if (__syncthreads_or(bad)) {
-    if (tid == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
+    if (tid == 0 && cidx_wg == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
     return;
   }
   const float* Bl = basis_all;
@@ -132,8 +134,8 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
   const float cfb = im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor;
   const float qb0 = im.qbias[0], qb1 = im.qbias[1], qb2 = im.qbias[2], qb3 = im.qbias[3];
   const int wp = im.wp, hp = im.hp;
-#pragma unroll 1
-  for (int cidx = 0; cidx < 3; cidx++) {
+  {
+    const int cidx = cidx_wg;
     const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
     const float qbc = c == 0 ? qb0 : (c == 1 ? qb1 : qb2);
     const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
@@ -492,11 +494,11 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
       (void)hipFuncSetAttribute((const void*)recon_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       raised = true;
     }
-    hipLaunchKernelGGL(recon_tile_kernel<true>, dim3(max_tiles, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
+    hipLaunchKernelGGL(recon_tile_kernel<true>, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
   } else {
     size_t lds = (size_t)(2 * kTS * kLP) * 4 + extra;
     if (getenv("JXLHIP_RECON_LDS")) lds = (size_t)atoi(getenv("JXLHIP_RECON_LDS"));
-    hipLaunchKernelGGL(recon_tile_kernel<false>, dim3(max_tiles, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
+    hipLaunchKernelGGL(recon_tile_kernel<false>, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
   }
 }
 

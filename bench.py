@@ -8,8 +8,9 @@ value = megapixels decoded per second, whole job (all ranks).  With --gpus N eac
 (weak scaling; independent images shard with no data-path collective — DESIGN.md "Multi-GPU").
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (the slowest of lf_ans_kernel / hf_decode_kernel / alpha_ans_kernel), bound = HBM;
-                achieved = algorithmic bytes per launch (B * (jxl bytes + W*H*4)) / its HIP-event duration
+  roofline      dominant kernel = the one with the most time per batch among lf_ans / hf_decode / alpha_ans / alpha_finish /
+                recon_tile / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
+                (jxl bytes + W*H*4)) / the average HIP-event duration of one launch
   cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
 """
 import argparse
@@ -49,7 +50,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "192")))
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "384")))
     ap.add_argument("--lane-stride", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="synchronise after every step (no cross-batch overlap)")
@@ -72,7 +73,15 @@ def main():
     data = open(FIXTURE, "rb").read()
     info = api.peek(data)
     W, H, C = info.width, info.height, info.num_channels
-    B = args.batch
+    # Batch per GPU: as many frames as the entropy stages can keep in flight (their time per batch is nearly constant), bounded by
+    # HBM: three pipeline slots of ~165 MB of entropy-stage state per frame, two output sets, and the shared pixel-stage planes.
+    free_b = torch.cuda.mem_get_info()[0]
+    fit = int((free_b * 0.88 - 26e9) / (3 * 165e6 + 2 * W * H * C))
+    B = max(1, min(args.batch, fit))
+    if world > 1:
+        t = torch.tensor([B], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        B = int(t.item())
     dec = api.Decoder(local_rank)
     dec.set_option("lane_stride", args.lane_stride)
     # inputs resident in HBM before the timed region (padded: the bit readers fetch whole 32-bit words)
@@ -134,16 +143,25 @@ def main():
     if rank == 0:
         mp = W * H / 1e6
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        kernels = {"lf_ans": "lf_ans_kernel", "hf_decode": "hf_decode_kernel", "alpha": "alpha_ans_kernel"}
-        dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))   # the dominant kernel of this run
-        dom_ms = stage_ms.get(dom, 0.0)
-        alg_bytes = B * (len(data) + W * H * C)
+        # stage -> (kernel, launches per batch, images per launch).  The pixel stages run in chunks of `chunk` frames that share one set
+        # of float planes, so their kernels are launched ceil(B / chunk) times per batch; the entropy kernels cover the whole batch.
+        chunk = dec.set_option("query_pixel_chunk", 0) or B
+        nchunks = (B + chunk - 1) // chunk
+        kernels = {"lf_ans": ("lf_ans_kernel", 1, B), "hf_decode": ("hf_decode_kernel", 1, B), "alpha_ans": ("alpha_ans_kernel", 1, B),
+                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile_kernel", nchunks, min(B, chunk)),
+                   "filters+output": ("filter_gab_epf1_kernel", nchunks, min(B, chunk))}
+        # the dominant kernel of this run: most time per batch
+        dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))
+        kname, launches, imgs_per_launch = kernels[dom]
+        dom_ms = stage_ms.get(dom, 0.0) / launches          # average duration of ONE launch of that kernel (HIP events on its stream)
+        alg_bytes = imgs_per_launch * (len(data) + W * H * C)
         # HBM traffic of that kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs, gfx950 correction 2*FETCH + WRITE per the micro-architecture guide), scaled to this batch
+        # --pmc WRITE_SIZE in separate runs, gfx950 correction 2*FETCH + WRITE per the micro-architecture guide), scaled to one launch
         traffic = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = int(pmc["kernels"][kernels[dom]]["hbm_bytes_per_image_corrected"] * B)
+            key = [k for k in pmc["kernels"] if k.startswith(kname)][0]
+            traffic = int(pmc["kernels"][key]["hbm_bytes_per_image_corrected"] * imgs_per_launch)
         except Exception:
             pass
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -163,9 +181,10 @@ def main():
             "config": {"workload": "3840x2160 RGBA8 lossy VarDCT (distance=1.0) decode, HBM-resident .jxl -> HBM RGBA8",
                        "batch_per_gpu": B, "jxl_bytes": len(data), "groups_per_image": info.num_groups,
                        "lane_stride": args.lane_stride or "auto", "async_steps": not args.sync_steps, "parallelism": "images sharded across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kernels[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(dom_ms, 4)},
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(dom_ms, 4), "launches_per_step": launches,
+                         "images_per_launch": imgs_per_launch},
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "single_image": {"latency_ms": round(min(lat), 3), "mp_per_s": round(mp / (min(lat) * 1e-3), 2),
                              "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()}},

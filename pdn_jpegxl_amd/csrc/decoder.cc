@@ -103,6 +103,7 @@ struct JxlHipDecoder {
     std::vector<float> stage_ms;
   };
   static constexpr int kSlots = 3;
+  static constexpr int kPixelChunk = 32;   // frames that share one set of reconstruction / filter planes
   Slot slots[kSlots];
   int cur = 0, last = 0;
   Slot* active = &slots[0];
@@ -335,11 +336,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t z_cellinfo, z_status, z_coef[3];
     std::vector<size_t> mod_planes;
-    size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end;
+    size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
   };
   std::vector<PerImg> L((size_t)n);
   int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
+  size_t chunk_pix = 0;   // padded pixels of the largest VarDCT frame of the batch
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
     const ParsedFrame& f = frames[i];
@@ -388,7 +390,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.blk_count = ws.Take((size_t)f.ng * 4);
     l.bitpos = ws.Take((size_t)f.ng * 8);
     l.tile_list = ws.Take(tiles * 4);
-    for (int c = 0; c < 3; c++) { l.tmp[c] = ws.Take(4 * pix); l.xyb[c] = ws.Take(4 * pix); }
+    l.alpha32 = ws.Take(4 * (size_t)f.xsize * f.ysize);
+    chunk_pix = std::max(chunk_pix, pix);
     l.inv_sigma = ws.Take(4 * cells);
     l.alpha = ws.Take((size_t)f.xsize * f.ysize);
     l.lf_end = ws.Take(8);
@@ -396,6 +399,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     total_lf += f.nlf;
     total_groups += f.ng;
   }
+  // The float planes between reconstruction and the loop filters (24 B/px) are only alive while a frame is in the pixel stages:
+  // frames go through those stages in chunks that share kPixelChunk sets of planes, so the batch size is bounded by the
+  // entropy-stage state (12 B/px of coefficients), not by 36 B/px.
+  const int pixel_chunk = debug_taps ? std::max(1, n) : std::min(std::max(1, n), kPixelChunk);
+  std::vector<size_t> chunk_tmp((size_t)pixel_chunk * 3), chunk_xyb((size_t)pixel_chunk * 3);
+  if (chunk_pix)
+    for (int k = 0; k < pixel_chunk * 3; k++) { chunk_tmp[k] = ws.Take(4 * chunk_pix); chunk_xyb[k] = ws.Take(4 * chunk_pix); }
   // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
   // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
   int lane_stride = 64;
@@ -602,7 +612,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.coef[c] = (int32_t*)(wz + l.z_coef[c]);
       d.lf[c] = (float*)(wr + l.lf[c]); d.lf_tmp[c] = (float*)(wr + l.lf_tmp[c]); d.lfq[c] = (int32_t*)(wr + l.lfq[c]);
       d.lf_final[c] = d.skip_lf_smoothing ? d.lf[c] : d.lf_tmp[c];
-      d.tmp[c] = (float*)(wr + l.tmp[c]); d.xyb[c] = (float*)(wr + l.xyb[c]);
+      d.tmp[c] = (float*)(wr + chunk_tmp[(size_t)(i % pixel_chunk) * 3 + c]); d.xyb[c] = (float*)(wr + chunk_xyb[(size_t)(i % pixel_chunk) * 3 + c]);
       d.xyb2[c] = (float*)d.coef[c];   // the coefficient planes are dead once the frame is reconstructed: loop-filter ping-pong buffer
     }
     d.lf_extra = wr + l.lf_extra;
@@ -613,7 +623,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.blk_list = (uint32_t*)(wr + l.blk_list); d.blk_count = (uint32_t*)(wr + l.blk_count);
     d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
     d.tile_list = (uint32_t*)(wr + l.tile_list);
-    d.alpha32 = (int32_t*)d.tmp[0];
+    d.alpha32 = (int32_t*)(wr + l.alpha32);
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
     d.lf_end_bits = (uint64_t*)(wr + l.lf_end);
@@ -700,20 +710,25 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // nothing but the bandwidth-bound pixel stages
   if (any_alpha)
     LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, s_hf);
+  Mark("alpha_ans", s_hf, 1);
   if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
   if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
-  Mark("alpha", s_hf, 1);
+  Mark("alpha_finish", s_hf, 1);
   if (s_hf != stream) {
     HIP_OK(hipEventRecord(S.hf_done, s_hf));
     HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
   }
   Mark("main_start", stream, 2);
-  LaunchReconTiles(d_imgs, n, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
-  LaunchGenericReconstruct(d_imgs, n, d_basis_all, d_basis_small, d_llf_scale, stream);
-  Mark("reconstruct", stream, 2);
-  if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
-  LaunchFilterTiles(d_imgs, n, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, stream);
-  Mark("filters+output", stream, 2);
+  for (int c0 = 0; c0 < n; c0 += pixel_chunk) {
+    const int cnt = std::min(pixel_chunk, n - c0);
+    LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
+    Mark("reconstruct", stream, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
+    LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, stream);
+    Mark("reconstruct_generic", stream, 2);
+    if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
+    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, stream);
+    Mark("filters+output", stream, 2);
+  }
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
@@ -944,6 +959,7 @@ DecoderStatus jxlhip_finish(JxlHipDecoder* dec, DecoderStatus* statuses, ErrorIn
 int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
   if (!dec || !name) return 0;
   if (!strcmp(name, "debug_taps")) { dec->debug_taps = value != 0; return 1; }
+  if (!strcmp(name, "query_pixel_chunk")) return JxlHipDecoder::kPixelChunk;
   if (!strcmp(name, "lane_stride")) { dec->lane_stride_override = value; return 1; }
   if (!strcmp(name, "band_first_row")) { dec->band_first_row = value; return 1; }
   if (!strcmp(name, "band_rows")) { dec->band_rows = value; return 1; }

@@ -22,6 +22,26 @@ constexpr int kLP = 65;       // LDS pitch (conflict-free column walks)
 __device__ const uint8_t t_quant_table[kNumStrategies] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
 
 __device__ __forceinline__ bool Special(uint32_t s) { return (s >= 1 && s <= 3) || (s >= 12 && s <= 17); }
+typedef float __attribute__((ext_vector_type(4))) F4;
+// a 16x16 sub-block (2x2 cells at even cell coordinates) goes to the matrix cores when the varblock of its top-left cell is at
+// least 16 points in both directions (varblocks are aligned to their size, so the sub-block then lies inside that one varblock)
+// One 16x16 output sub-block: acc = sum_k A[k] * B[k] with both operand streams fetched up front (N / 4 independent loads
+// each, one wait) so that the MFMA chain is not paced by a memory round trip per step.  pa / pb: lane's first operand;
+// sa / sb: stride between consecutive k-steps of four.
+template <int N>
+__device__ __forceinline__ F4 MfmaChain(const float* pa, int sa, const float* pb, int sb) {
+  float a[N / 4], b[N / 4];
+#pragma unroll
+  for (int k = 0; k < N / 4; k++) { a[k] = pa[k * sa]; b[k] = pb[k * sb]; }
+  F4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < N / 4; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ F4 MfmaChainN(int n, const float* pa, int sa, const float* pb, int sb) {
+  return n == 16 ? MfmaChain<16>(pa, sa, pb, sb) : (n == 32 ? MfmaChain<32>(pa, sa, pb, sb) : MfmaChain<64>(pa, sa, pb, sb));
+}
+__device__ __forceinline__ bool MfmaSubBlock(uint32_t info) { return (info >> 31) && ((info >> 18) & 7) >= 1 && ((info >> 21) & 7) >= 1; }
 __device__ __forceinline__ int Mirror(int v, int n) {
   while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
   return v;
@@ -142,8 +162,8 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
     const float cfl = c == 0 ? cfx : (c == 1 ? 0.f : cfb);
     const int32_t* qc = im.coef[c];
     const int32_t* qy = im.coef[1];
-    // ---- dequantisation (+ chroma from luma).  Fully unrolled with unconditional (clamped) loads so that the 16
-    // coefficient / weight fetches of a thread are in flight together instead of one round trip per element.
+    // ---- dequantisation (+ chroma from luma).  Unconditional (clamped) loads, two iterations in flight (hoisting all sixteen
+    // coefficient fetches ahead of the weight gathers was measured: no gain, and the registers cost two workgroups per CU).
 #pragma unroll 2
     for (int it = 0; it < 16; it++) {
       const int e = tid + it * 256;
@@ -217,11 +237,32 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
       }
     }
     __syncthreads();
-    // ---- vertical pass -> tmpb.  One thread = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
+    // ---- vertical pass -> tmpb.
+    // Matrix cores for everything that is at least 16 points in both directions (97 % of this fixture's area): the tile is cut
+    // into sixteen 16x16 sub-blocks, four per wavefront; a sub-block that lies inside one varblock of R rows is the product
+    // Basis_R^T (16 x R) * coefficients (R x 16), accumulated by v_mfma_f32_16x16x4_f32 (exact f32, the same k-ordered fma
+    // chain as the VALU path).  Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], and owns D[4 * (l >> 4) + r][l & 15].
+    const int wave = tid >> 6, l16 = tid & 15, lq = (tid & 63) >> 4;
+    if (!(ablate & 2)) {
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int sb = wave * 4 + s4;
+        const uint32_t inf = ci[(sb >> 2) * 16 + (sb & 3) * 2];
+        if (MfmaSubBlock(inf)) {   // wave-uniform
+          const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
+          const int cy0 = (sb >> 2) * 2, x0 = (sb & 3) * 16;
+          const float* B = (R == 16 ? B816 + 64 : Bl + (R * R - 64) / 3) + lq * R + iy * 8 + l16;
+          const float* cp = cfc + ((cy0 - iy) * 8 + lq) * kLP + x0 + l16;
+          const F4 acc = MfmaChainN(R, B, 4 * R, cp, 4 * kLP);
+          float* o = tmpb + (cy0 * 8 + 4 * lq) * kLP + x0 + l16;
+          o[0] = acc.x; o[kLP] = acc.y; o[2 * kLP] = acc.z; o[3 * kLP] = acc.w;
+        }
+      }
+    }
+    // the rest on the vector ALUs.  One thread = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
     if (!(ablate & 2)) {
       const int x = (tid & 31) * 2, cr = tid >> 5;
       const uint32_t info = ci[cr * 8 + (x >> 3)];
-      if (info >> 31) {
+      if ((info >> 31) && !MfmaSubBlock(ci[(cr >> 1) * 16 + (x >> 4) * 2])) {
         const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
         const int R = 8 << lcy;
         const float* in = cfc + (cr - iy) * 8 * kLP + x;
@@ -251,11 +292,27 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
       }
     }
     __syncthreads();
-    // ---- horizontal pass: tmpb -> cfc (the coefficients of this channel are dead now).  Two adjacent rows per thread.
+    // ---- horizontal pass: tmpb -> cfc (the coefficients of this channel are dead now): rows (16 x C) * Basis_C (C x 16).
+    if (!(ablate & 2)) {
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int sb = wave * 4 + s4;
+        const uint32_t inf = ci[(sb >> 2) * 16 + (sb & 3) * 2];
+        if (MfmaSubBlock(inf)) {
+          const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
+          const int cx0 = (sb & 3) * 2, y0 = (sb >> 2) * 16;
+          const float* B = (C == 16 ? B816 + 64 : Bl + (C * C - 64) / 3) + lq * C + ix * 8 + l16;
+          const float* ap = tmpb + (y0 + l16) * kLP + (cx0 - ix) * 8 + lq;
+          const F4 acc = MfmaChainN(C, ap, 4, B, 4 * C);
+          float* o = cfc + (y0 + 4 * lq) * kLP + cx0 * 8 + l16;
+          o[0] = acc.x; o[kLP] = acc.y; o[2 * kLP] = acc.z; o[3 * kLP] = acc.w;
+        }
+      }
+    }
+    // the rest: two adjacent rows per thread
     if (!(ablate & 2)) {
       const int y = (tid & 31) * 2, cc = tid >> 5;
       const uint32_t info = ci[(y >> 3) * 8 + cc];
-      if (info >> 31) {
+      if ((info >> 31) && !MfmaSubBlock(ci[(y >> 4) * 16 + (cc >> 1) * 2])) {
         const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
         const int C = 8 << lcx;
         const float* in = tmpb + y * kLP + (cc - ix) * 8;

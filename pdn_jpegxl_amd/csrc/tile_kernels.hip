@@ -47,7 +47,11 @@ __device__ __forceinline__ int Mirror(int v, int n) {
   return v;
 }
 
-__device__ __forceinline__ float SrgbOetfT(float v) { return v <= 0.0031308f ? 12.92f * v : 1.055f * powf(v, 1.0f / 2.4f) - 0.055f; }
+// v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
+// * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
+__device__ __forceinline__ float SrgbOetfT(float v) {
+  return v <= 0.0031308f ? 12.92f * v : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
+}
 __device__ __forceinline__ uint8_t ToU8T(float v) {
   v *= 255.0f;
   if (!(v > 0.f)) return 0;
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
 // XYB with a 3-pixel halo is staged in LDS, the Gaborish result (2-pixel halo, what the EPF reads) is written to a second LDS
 // tile, the EPF runs from there.  Out-of-frame positions are filled through the mirrored input, which gives the mirrored
 // Gaborish value because the 3x3 kernel is symmetric.  Saves one 24 B/px round trip through HBM and one launch.
-__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs, int ablate) {
   constexpr int TW = 32, TH = 32, HI = 3, HG = 2;
   constexpr int IW = TW + 2 * HI, IH = TH + 2 * HI, GW = TW + 2 * HG, GH = TH + 2 * HG;
   __shared__ float s_in[3][IH][IW + 1];
@@ -471,7 +475,7 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     const int e = e0 < IW * IH ? e0 : IW * IH - 1;
     const int ly = e / IW, lx = e % IW;
     const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
-    const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
+    const float v0 = (ablate & 1) ? (float)lx : in0[g], v1 = (ablate & 1) ? (float)ly : in1[g], v2 = (ablate & 1) ? 0.5f : in2[g];
     s_in[0][ly][lx] = v0;
     s_in[1][ly][lx] = v1;
     s_in[2][ly][lx] = v2;
@@ -488,8 +492,20 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     }
   }
   __syncthreads();
-  const int off1[4][2] = {{-1, 0}, {0, -1}, {0, 1}, {1, 0}};
-  const int plus[5][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}};
+  // Channel-weighted absolute differences between horizontal / vertical neighbours, once per pair: the SAD of a pixel against its
+  // neighbour over the plus-shaped support is then five reads instead of thirty.  The tiles overlay the (now dead) input tile.
+  float (*dh)[GW + 1] = (float (*)[GW + 1])&s_in[0][0][0];          // dh[y][x] = sum_c scale_c |t_c[y][x] - t_c[y][x + 1]|
+  float (*dv)[GW + 1] = (float (*)[GW + 1])(&s_in[0][0][0] + GH * (GW + 1));   // dv[y][x] = ... |t_c[y][x] - t_c[y + 1][x]|
+  static_assert(2 * GH * (GW + 1) <= 3 * IH * (IW + 1), "difference tiles must fit the input tile");
+  const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
+  for (int e = threadIdx.x; e < GW * GH; e += 256) {
+    const int gy = e / GW, gx = e % GW;
+    if (gx + 1 < GW)
+      dh[gy][gx] = fabsf(t[0][gy][gx] - t[0][gy][gx + 1]) * cs0 + fabsf(t[1][gy][gx] - t[1][gy][gx + 1]) * cs1 + fabsf(t[2][gy][gx] - t[2][gy][gx + 1]) * cs2;
+    if (gy + 1 < GH)
+      dv[gy][gx] = fabsf(t[0][gy][gx] - t[0][gy + 1][gx]) * cs0 + fabsf(t[1][gy][gx] - t[1][gy + 1][gx]) * cs1 + fabsf(t[2][gy][gx] - t[2][gy + 1][gx]) * cs2;
+  }
+  __syncthreads();
 #pragma unroll 2
   for (int e = threadIdx.x; e < TW * TH; e += 256) {
     const int ly = e / TW, lx = e % TW;
@@ -498,31 +514,22 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     const int cy = ly + HG, cx = lx + HG;
     const float is = im.inv_sigma[(size_t)(y >> 3) * im.w8 + (x >> 3)];
     float o0 = t[0][cy][cx], o1 = t[1][cy][cx], o2 = t[2][cy][cx];
-    if (!(is < -3.90524291751269967465540850526868f)) {
+    if (!(is < -3.90524291751269967465540850526868f) && !(ablate & 2)) {
       const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
       const float inv = is * (border ? im.epf_border_sad_mul : 1.0f);
-      float wsum = 1.0f;
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int dy = off1[k][0], dx = off1[k][1];
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int p = 0; p < 5; p++) {
-          const int ay = cy + plus[p][0], ax = cx + plus[p][1];
-          s0 += fabsf(t[0][ay][ax] - t[0][ay + dy][ax + dx]);
-          s1 += fabsf(t[1][ay][ax] - t[1][ay + dy][ax + dx]);
-          s2 += fabsf(t[2][ay][ax] - t[2][ay + dy][ax + dx]);
-        }
-        const float sad = s0 * im.epf_channel_scale[0] + s1 * im.epf_channel_scale[1] + s2 * im.epf_channel_scale[2];
-        const float wt = fmaxf(0.0f, 1.0f + sad * inv);
-        wsum += wt;
-        o0 += wt * t[0][cy + dy][cx + dx];
-        o1 += wt * t[1][cy + dy][cx + dx];
-        o2 += wt * t[2][cy + dy][cx + dx];
-      }
-      const float iw = 1.0f / wsum;
-      o0 *= iw; o1 *= iw; o2 *= iw;
+      // SAD against the neighbour above / left / right / below, summed over the support {centre, up, down, left, right}
+      const float sad_u = dv[cy - 1][cx] + dv[cy - 2][cx] + dv[cy][cx] + dv[cy - 1][cx - 1] + dv[cy - 1][cx + 1];
+      const float sad_l = dh[cy][cx - 1] + dh[cy - 1][cx - 1] + dh[cy + 1][cx - 1] + dh[cy][cx - 2] + dh[cy][cx];
+      const float sad_r = dh[cy][cx] + dh[cy - 1][cx] + dh[cy + 1][cx] + dh[cy][cx - 1] + dh[cy][cx + 1];
+      const float sad_d = dv[cy][cx] + dv[cy - 1][cx] + dv[cy + 1][cx] + dv[cy][cx - 1] + dv[cy][cx + 1];
+      const float w_u = fmaxf(0.0f, 1.0f + sad_u * inv), w_l = fmaxf(0.0f, 1.0f + sad_l * inv);
+      const float w_r = fmaxf(0.0f, 1.0f + sad_r * inv), w_d = fmaxf(0.0f, 1.0f + sad_d * inv);
+      const float iw = 1.0f / (1.0f + w_u + w_l + w_r + w_d);
+      o0 = (o0 + w_u * t[0][cy - 1][cx] + w_l * t[0][cy][cx - 1] + w_r * t[0][cy][cx + 1] + w_d * t[0][cy + 1][cx]) * iw;
+      o1 = (o1 + w_u * t[1][cy - 1][cx] + w_l * t[1][cy][cx - 1] + w_r * t[1][cy][cx + 1] + w_d * t[1][cy + 1][cx]) * iw;
+      o2 = (o2 + w_u * t[2][cy - 1][cx] + w_l * t[2][cy][cx - 1] + w_r * t[2][cy][cx + 1] + w_d * t[2][cy + 1][cx]) * iw;
     }
+    if (ablate & 4) { ((uchar4*)im.out)[(size_t)(y - im.band_y0) * im.w + x] = make_uchar4((uint8_t)(o0 * 255.f), (uint8_t)(o1 * 255.f), (uint8_t)(o2 * 255.f), 255); continue; }
     WritePixel(im, x, y, o0, o1, o2);
   }
 }
@@ -563,7 +570,10 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
                        bool any_fused, hipStream_t s) {
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
-  if (any_fused) hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs);
+  if (any_fused) {
+    static const int ablate_f = getenv("JXLHIP_ABLATE_F") ? atoi(getenv("JXLHIP_ABLATE_F")) : 0;
+    hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs, ablate_f);
+  }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 1) hipLaunchKernelGGL(filter_tile_kernel<2>, g, dim3(256), 0, s, imgs);

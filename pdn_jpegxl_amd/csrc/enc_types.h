@@ -25,7 +25,7 @@ struct EncCodeDev {
   const uint16_t* freq;    // [cluster * kEncSyms + symbol]
   const uint16_t* start;
   const uint16_t* rmap;    // [cluster * 4096 + start + offset]
-  uint32_t num_clusters, pad;
+  uint32_t num_clusters, num_ctx;
 };
 
 struct EncImage {

@@ -383,33 +383,98 @@ struct LaneWriter {
 // rANS with 12-bit precision and 16-bit renormalisation.  The decoder consumes the stream front to back, so the state
 // is run over the tokens back to front (recording what each step flushes), then the bits are laid out front to back.
 __device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, LaneWriter& w) {
+  // Both passes walk the token array in blocks of eight with the next block already in flight: the array lives in HBM and a
+  // lane that waits for every token pays a full memory round trip per token (the state recurrence itself is ~40 instructions).
+  // (tokens are read as DevToken, the type they are written as: the forward pass must see the flushes of the reverse pass)
+  const DevToken kNone = {0u, 0u};
   uint32_t state = 0x130000u;
-  for (uint32_t r = n; r-- > 0;) {
-    const uint32_t cl = code.ctx_map[tok[r].ctx];
-    uint32_t sym, nb, bits;
-    HybridD(tok[r].value, &sym, &nb, &bits);
-    const uint32_t freq = code.freq[cl * kEncSyms + sym];
-    uint32_t flush = 0;
-    if ((state >> 20) >= freq) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
-    const uint32_t qd = state / freq, rm = state - qd * freq;
-    state = (qd << 12) + code.rmap[(size_t)cl * 4096 + code.start[cl * kEncSyms + sym] + rm];
-    tok[r].ctx = flush;
+  {
+    DevToken cur[8], nxt[8];
+    int64_t base = (int64_t)n - 8;   // block [base, base + 8) clipped to [0, n)
+#pragma unroll
+    for (int k = 0; k < 8; k++) cur[k] = base + k >= 0 ? tok[base + k] : kNone;
+    for (; base > -8; base -= 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) nxt[k] = base - 8 + k >= 0 ? tok[base - 8 + k] : kNone;
+#pragma unroll
+      for (int k = 7; k >= 0; k--) {
+        const int64_t r = base + k;
+        if (r < 0) continue;
+        const uint32_t ctx = cur[k].ctx, value = cur[k].value;
+        const uint32_t cl = code.ctx_map[ctx];
+        uint32_t sym, nb, bits;
+        HybridD(value, &sym, &nb, &bits);
+        const uint32_t freq = code.freq[cl * kEncSyms + sym];
+        uint32_t flush = 0;
+        if ((state >> 20) >= freq) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
+        const uint32_t qd = state / freq, rm = state - qd * freq;
+        state = (qd << 12) + code.rmap[(size_t)cl * 4096 + code.start[cl * kEncSyms + sym] + rm];
+        tok[r].ctx = flush;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+    }
   }
   w.Put(32, state);
-  for (uint32_t i = 0; i < n; i++) {
-    const uint32_t flush = tok[i].ctx;
-    uint32_t sym, nb, bits;
-    HybridD(tok[i].value, &sym, &nb, &bits);
-    if (flush) w.Put(16, flush & 0xFFFF);
-    w.Put((int)nb, bits);
+  {
+    DevToken cur[8], nxt[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cur[k] = (uint32_t)k < n ? tok[k] : kNone;
+    for (uint32_t base = 0; base < n; base += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) nxt[k] = base + 8 + k < n ? tok[base + 8 + k] : kNone;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (base + k >= n) continue;
+        const uint32_t flush = cur[k].ctx, value = cur[k].value;
+        uint32_t sym, nb, bits;
+        HybridD(value, &sym, &nb, &bits);
+        if (flush) w.Put(16, flush & 0xFFFF);
+        w.Put((int)nb, bits);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+    }
   }
 }
 
 }  // namespace
 
-// sections [0, nlf): LF groups; [nlf, nlf + ng): pass groups
+namespace {
+
+// Copies the small tables of a code (context map, frequencies, cumulative starts; the slot map too when `with_rmap`) into LDS:
+// a token then costs at most one dependent global load (the slot map of the big HF code) instead of three.
+__device__ size_t StageEncCode(uint8_t* smem, size_t off, const EncCodeDev& g, EncCodeDev* l, bool with_rmap, int tid, int nt) {
+  off = (off + 15) & ~(size_t)15;
+  const size_t nfs = (size_t)g.num_clusters * kEncSyms;
+  uint16_t* f = (uint16_t*)(smem + off); off += nfs * 2;
+  uint16_t* st = (uint16_t*)(smem + off); off += nfs * 2;
+  uint16_t* rm = (uint16_t*)(smem + off);
+  if (with_rmap) off += (size_t)g.num_clusters * 4096 * 2;
+  uint8_t* m = smem + off; off += g.num_ctx;
+  for (size_t i = tid; i < nfs; i += nt) { f[i] = g.freq[i]; st[i] = g.start[i]; }
+  if (with_rmap) for (size_t i = tid; i < (size_t)g.num_clusters * 4096; i += nt) rm[i] = g.rmap[i];
+  for (size_t i = tid; i < g.num_ctx; i += nt) m[i] = g.ctx_map[i];
+  l->ctx_map = m; l->freq = f; l->start = st; l->rmap = with_rmap ? rm : g.rmap;
+  l->num_clusters = g.num_clusters; l->num_ctx = g.num_ctx;
+  return off;
+}
+
+}  // namespace
+
+// sections [0, nlf): LF groups; [nlf, nlf + ng): pass groups.  kSectionsPerWg lanes of a workgroup own one section each.
+constexpr int kSectionsPerWg = 8;
 __global__ __launch_bounds__(64) void enc_sections_kernel(EncImage im) {
-  const int s = blockIdx.x * 64 + threadIdx.x;
+  extern __shared__ __align__(16) uint8_t enc_smem[];
+  {
+    EncCodeDev lm, la;
+    size_t off = StageEncCode(enc_smem, 0, im.mcode, &lm, true, threadIdx.x, 64);
+    StageEncCode(enc_smem, off, im.acode, &la, false, threadIdx.x, 64);
+    im.mcode = lm; im.acode = la;
+    __syncthreads();
+  }
+  if ((int)threadIdx.x >= kSectionsPerWg) return;
+  const int s = blockIdx.x * kSectionsPerWg + threadIdx.x;
   if (s >= im.nlf + im.ng) return;
   LaneWriter w;
   w.Init(im.sec_bytes + (size_t)s * im.sec_cap);
@@ -543,7 +608,11 @@ void LaunchEncTokens(const EncImage& im, hipStream_t s) {
   if (im.has_alpha) hipLaunchKernelGGL(enc_alpha_tokens_kernel, dim3(32, im.ng), dim3(256), 0, s, im);
 }
 void LaunchEncSections(const EncImage& im, hipStream_t s) {
-  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + 63) / 64)), dim3(64), 0, s, im);
+  // LDS: modular code with its slot map + HF code without (sizes as StageEncCode carves them)
+  const size_t lds = 64 + (size_t)im.mcode.num_clusters * (kEncSyms * 4 + 8192) + im.mcode.num_ctx + (size_t)im.acode.num_clusters * kEncSyms * 4 +
+                     im.acode.num_ctx;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_sections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64), lds, s, im);
   if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
 }
 void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s) {

@@ -7,6 +7,7 @@
 // reference delegates to libjxl (JxlEncoderAddImageFrame :128, JxlEncoderFlushInput :367) runs in encode_kernels.hip.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -70,6 +71,19 @@ struct Arena {
   }
 };
 
+// JXLHIP_ENC_TIMING=1: wall time of the encoder's phases on stderr (host + device, synchronised at each checkpoint)
+struct PhaseClock {
+  bool on = getenv("JXLHIP_ENC_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void Lap(const char* what) {
+    if (!on) return;
+    (void)hipDeviceSynchronize();
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[enc] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 void Progress(ProgressProc progress, int percent) {
   if (progress && !progress(percent)) throw EncFail(EncoderStatus_UserCanceled, "");   // Encoder/JxlEncoder.cpp:79-89
 }
@@ -113,7 +127,7 @@ EncCodeDev UploadCode(Arena& A, const EncCode& c) {
   d.start = A.Upload(c.start);
   d.rmap = A.Upload(c.rmap);
   d.num_clusters = c.num_clusters;
-  d.pad = 0;
+  d.num_ctx = (uint32_t)c.ctx_map.size();
   return d;
 }
 
@@ -248,7 +262,9 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   Arena A;
   hipStream_t s = nullptr;
   EncImage im;
+  PhaseClock clk;
   BeginImage(bmp, md, A, im, progress);
+  clk.Lap("upload + analysis");
   const uint32_t w = bmp->width, h = bmp->height;
   const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
   // ---- 2. quantiser and loop-filter parameters (only distance comes from the options, :319; effort is not used)
@@ -291,7 +307,9 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.rawq = A.Get<int32_t>(ncell);
   if (im.has_alpha) im.alpha_px = A.Get<int32_t>(npx);
   Progress(progress, 15);
+  clk.Lap("allocation");
   LaunchEncFrontEnd(im, s);
+  clk.Lap("xyb + sharpen + dct/quant");
   Progress(progress, 20);
   // ---- 4. tokens + histograms
   im.tok_lf = A.Get<DevToken>((size_t)im.nlf * kLfTokCap);
@@ -305,6 +323,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   std::vector<uint32_t> hist_mod(kNumEncLeaves * kEncSyms), hist_ac((size_t)kAcContexts * kEncSyms);
   ENC_HIP(hipMemcpy(hist_mod.data(), im.hist_mod, hist_mod.size() * 4, hipMemcpyDeviceToHost));
   ENC_HIP(hipMemcpy(hist_ac.data(), im.hist_ac, hist_ac.size() * 4, hipMemcpyDeviceToHost));
+  clk.Lap("tokens + histograms");
   Progress(progress, 25);
   // ---- 5. LfGlobal and HfGlobal (host): quantiser, MA tree, entropy codes
   const bool single = im.ng == 1;
@@ -327,6 +346,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   hf_global.Write(im.ng <= 1 ? 0 : 32 - __builtin_clz((unsigned)(im.ng - 1)), 0);   // one HF preset
   hf_global.U32(WV(0x5F), WV(0x13), WV(0), WB(kNumOrders), 0);                       // natural coefficient orders
   BuildAndWriteCode(hist_ac.data(), kAcContexts, 64, {}, hf_global, acode);
+  clk.Lap("host: tree + codes");
   // ---- 6. ANS coding of every section on the GPU
   im.mcode = UploadCode(A, mcode);
   im.acode = UploadCode(A, acode);
@@ -335,6 +355,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
   im.sec_bits = A.Get<uint64_t>(nsec, true);
   LaunchEncSections(im, s);
+  clk.Lap("ans sections");
   std::vector<uint64_t> sec_bits(nsec);
   ENC_HIP(hipMemcpy(sec_bits.data(), im.sec_bits, sec_bits.size() * 8, hipMemcpyDeviceToHost));
   std::vector<uint64_t> off(nsec + 1, 0);
@@ -347,6 +368,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
     ENC_HIP(hipMemcpy(packed.data(), d_packed, packed.size(), hipMemcpyDeviceToHost));
   }
   ENC_HIP(hipGetLastError());
+  clk.Lap("compact + download");
   Progress(progress, 30);
   // ---- 7. codestream assembly
   EncImageInfo ii;
@@ -375,7 +397,9 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   WriteToc(sizes, cs);
   std::vector<uint8_t> codestream = cs.Finish();
   for (auto& sec : sections) codestream.insert(codestream.end(), sec.begin(), sec.end());
+  clk.Lap("assembly");
   EmitFile(codestream, md, io, progress);
+  clk.Lap("container + write callbacks");
 }
 
 }  // namespace

@@ -1,0 +1,34 @@
+"""Manual robustness campaign (not a test): random byte corruptions of valid streams must end in Ok or a clean error, never a hang
+or a GPU fault.  Run on the GPU box:  timeout -k 10 300 python tools/fuzz_gpu.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as O
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+rng = np.random.default_rng(7)
+img = synth(300, 280, 3)
+streams = [O.encode(img, distance=1.0), O.encode(img, distance=2.0, strategy_mode=2, seed=4), O.encode(img, lossless=True),
+           O.encode(img, lossless=True, lossless_squeeze=True), O.encode(synth(64, 48, 5))]
+counts = {}
+for si, data in enumerate(streams):
+    for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 25):
+        d = bytearray(data)
+        lo = 40 + (trial % 7) * 20                 # spare the signature; corrupt headers and payloads alike
+        for _ in range(1 + trial % 4):
+            p = int(rng.integers(lo, len(d)))
+            d[p] ^= int(rng.integers(1, 256))
+        try:
+            api.load_image(bytes(d))
+            k = "ok"
+        except api.JxlError as e:
+            k = e.status
+        counts[k] = counts.get(k, 0) + 1
+    print("stream", si, counts, flush=True)
+print("done", counts)

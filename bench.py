@@ -66,9 +66,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+    # Rehearsal hook for a one-GPU box (the real multi-GPU run uses one device per rank and RCCL): JXLHIP_BENCH_REHEARSAL=1 puts
+    # every rank on device 0 and runs the (tiny, non-data-path) collectives over gloo.
+    rehearsal = os.environ.get("JXLHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    coll_dev = "cpu" if rehearsal else "cuda"
 
     data = open(FIXTURE, "rb").read()
     info = api.peek(data)
@@ -79,7 +85,7 @@ def main():
     fit = int((free_b * 0.88 - 26e9) / (3 * 165e6 + 2 * W * H * C))
     B = max(1, min(args.batch, fit))
     if world > 1:
-        t = torch.tensor([B], dtype=torch.int64, device="cuda")
+        t = torch.tensor([B], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         B = int(t.item())
     dec = api.Decoder(local_rank)
@@ -127,7 +133,7 @@ def main():
     stage_sum, nb = dec.stage_totals(reset=True)
     assert nb == args.steps, (nb, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -533,37 +533,44 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
     return;
   }
   JXL_GLB int32_t* const out = G(out_generic);
-  JXL_GLB int32_t* row = out;
-  typename AS<kLds>::U64 abase = tab.alias;
-  uint32_t cfg = 0, mul = 1, off = 0, cres = 0, pred = 0, W = 0, first_prev = 0, first_cur = 0;
-  bool ctok = false;
-  int x = 0, y = 0;
-  while (y < h) {
-    if (x == 0) {
-      bool used_y = false;
-      const DevTreeNode nd = RowNode(tree, chan, sid, y, &used_y);
-      const uint32_t cl = tab.cmap[nd.a >> 8];
-      cfg = tab.cfg[cl];
-      abase = tab.alias + (cl << tab.log_alpha);
-      mul = nd.b; off = (uint32_t)nd.splitval; pred = nd.a & 0xFF;
-      const uint32_t sym = (cfg >> 16) & 0xFF;
-      ctok = (cfg & 0x1000) && sym < (1u << (cfg & 0xF));
-      cres = (uint32_t)UnpackSigned(sym) * mul + off;
-      row = out + (size_t)y * stride;
+  uint32_t first_prev = 0;   // sample (0, y - 1): what West means at the start of a row
+  for (int y = 0; y < h; y++) {
+    // row constants: leaf -> cluster, hybrid-uint config, multiplier / offset, predictor
+    bool used_y = false;
+    const DevTreeNode nd = RowNode(tree, chan, sid, y, &used_y);
+    const uint32_t cl = tab.cmap[nd.a >> 8];
+    const uint32_t cfg = tab.cfg[cl];
+    const typename AS<kLds>::U64 abase = tab.alias + (cl << tab.log_alpha);
+    const uint32_t mul = nd.b, off = (uint32_t)nd.splitval;
+    const bool add_w = !needs_n && (nd.a & 0xFF) == 1;   // Zero / West rows need no row above: finished inline
+    const uint32_t csym = (cfg >> 16) & 0xFF;
+    const bool ctok = (cfg & 0x1000) && csym < (1u << (cfg & 0xF));
+    const uint32_t cres = (uint32_t)UnpackSigned(csym) * mul + off;
+    JXL_GLB int32_t* const row = out + (size_t)y * stride;
+    uint32_t W = y ? first_prev : 0u;
+    if (ctok) {   // a row of one-symbol tokens: nothing is read from the stream
+      for (int x = 0; x < w; x++) {
+        const uint32_t val = cres + (add_w ? W : 0u);
+        row[x] = (int32_t)val;
+        W = val;
+      }
+      first_prev = cres + (add_w ? (y ? first_prev : 0u) : 0u);
+      continue;
     }
-    if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
-    uint32_t val;
-    if (ctok) val = cres;
-    else {
-      const uint32_t sym = AnsSym<kLds>(b, state, abase, tab.log_alpha);
-      val = (uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * mul + off;
+    // sixteen tokens per top-up of the bit window; no per-token bookkeeping beyond the decode itself
+    uint32_t first = 0;
+    for (int x0 = 0; x0 < w; x0 += kTopUpEvery) {
+      b.TopUp();
+      const int xe = min(w, x0 + kTopUpEvery);
+      for (int x = x0; x < xe; x++) {
+        const uint32_t sym = AnsSym<kLds>(b, state, abase, tab.log_alpha);
+        const uint32_t val = (uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * mul + off + (add_w ? W : 0u);
+        row[x] = (int32_t)val;
+        W = val;
+        first = x == 0 ? val : first;
+      }
     }
-    // Zero / West predictors need no row above: applied inline unless the channel goes through phase B anyway
-    if (!needs_n && pred == 1) val += x == 0 ? (y ? first_prev : 0u) : W;
-    row[x] = (int32_t)val;
-    W = val;
-    if (x == 0) first_cur = val;
-    if (++x == w) { x = 0; y++; first_prev = first_cur; }
+    first_prev = first;
   }
   d.kind = needs_n ? kChanResid : kChanFinal;
   *desc = d;

@@ -945,6 +945,14 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
   if (lane == 0) im.blk_count[g] = total;
 }
 
+__device__ __noinline__ void StoreViaGlobalOrder(const uint16_t* order, uint32_t k, uint32_t lng_log2, bool transposed, JXL_GLB int32_t* plane,
+                                                 int wp, int32_t value) {
+  const uint32_t p = order[k];
+  const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
+  const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
+  plane[(size_t)ky * wp + kx] = value;
+}
+
 // One lane per group section (lane_stride spreads sections over wavefronts).  The loop decodes exactly one token per
 // iteration: the number-of-nonzeros token of a (block, channel) or one coefficient token.  Per-lane state that the
 // context model needs (non-zero counts of the row above / the cell to the left) is a 32-entry column buffer per
@@ -1098,14 +1106,19 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
         ci++;
       }
     } else {
-      uint32_t p = pnext;
+      const uint32_t p = pnext;
       const uint32_t k1 = k + 1 < size ? k + 1 : k;
       pnext = lds_orders[lorder + (order_staged ? k1 : 0u)];
       if (u) {
-        if (!order_staged) p = G(im.order[ord * 3 + c])[k];   // rare; the only global load of the loop, waited for in this branch
-        const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
-        const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-        plane[(size_t)ky * wp + kx] = UnpackSigned(u);
+        if (order_staged) {
+          const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
+          const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
+          plane[(size_t)ky * wp + kx] = UnpackSigned(u);
+        } else {
+          // blocks of 128 points and up / custom orders: the order entry comes from global memory.  Out of line on purpose: a load
+          // whose result merged into the common path made the compiler wait for ALL outstanding stores before every coefficient store.
+          StoreViaGlobalOrder(im.order[ord * 3 + c], k, lng_log2, transposed, plane, wp, UnpackSigned(u));
+        }
         prev = 1;
         if (--nzeros == 0) { want_nz = true; ci++; }
       } else {

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   JXL_GLB int32_t* const coef2 = G(im.coef[2]);
   bool want_nz = true;
   while (!err) {
-    if ((it++ & (kTopUpEvery - 1)) == 0) {
+    if ((it & (kTopUpEvery - 1)) == 0) {
       // a token consumes at most 48 bits and starts at most one block: 16 tokens never outrun 24 words / 6 descriptors
       b.TopUp();
       const uint32_t lim = min(nblk, bi + 8);
@@ -1052,6 +1052,38 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
         for (int i = 0; i < 8; i++) if (dfilled + i < lim) dq[(size_t)((dfilled + i) & 7) * nslots] = v[i];
         dfilled = lim;
       }
+    }
+    // Fast path: while every lane of the wavefront that is still decoding sits inside a run of coefficient tokens (always the
+    // case with one section per wavefront, i.e. small batches), stay in a loop that holds nothing but the coefficient token:
+    // the general iteration below pays for both token kinds and their bookkeeping on every step.
+    if (__all(!want_nz)) {
+      for (;;) {
+        const uint32_t nzl = (nzeros + covered - 1) >> log2c;
+        const uint32_t ks = k >> log2c;
+        const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 15 + ((ks - 16) >> 1) : 23 + ((ks - 32) >> 2));
+        const uint32_t u = AnsGet(b, state, tab, histo + ((uint32_t)nnz_tab[nzl] + fctx) * 2 + prev);
+        it++;
+        const uint32_t p = pnext;
+        const uint32_t k1 = k + 1 < size ? k + 1 : k;
+        pnext = lds_orders[lorder + (order_staged ? k1 : 0u)];
+        bool leave = false;
+        if (u) {
+          if (order_staged) {
+            const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
+            const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
+            plane[(size_t)ky * wp + kx] = UnpackSigned(u);
+          } else {
+            StoreViaGlobalOrder(im.order[ord * 3 + (ci == 0 ? 1 : (ci == 1 ? 0 : 2))], k, lng_log2, transposed, plane, wp, UnpackSigned(u));
+          }
+          prev = 1;
+          if (--nzeros == 0) { want_nz = true; ci++; leave = true; }
+        } else {
+          prev = 0;
+        }
+        if (++k >= size && nzeros != 0) { err |= kErrBitstream; leave = true; }
+        if (__any(leave) || (it & (kTopUpEvery - 1)) == 0) break;
+      }
+      continue;
     }
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
@@ -1086,6 +1118,7 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
       ctx = histo + ((uint32_t)nnz_tab[nzl] + fctx) * 2 + prev;
     }
     const uint32_t u = AnsGet(b, state, tab, ctx);
+    it++;
     if (want_nz) {
       nzeros = u;
       if (nzeros + covered > size) { err |= kErrBitstream; break; }

@@ -503,3 +503,30 @@ extern "C" JXLFILETYPEIO_API int32_t jxlhip_selftest_tree(uint32_t nlf, ErrorInf
     return 6;
   }
 }
+
+// Writes the codestream headers + frame header + TOC the encoder would emit for the given geometry (sections of `sec_bytes` bytes each)
+// into dst; the CPU tests read them back with jxlhip_peek (ParseFile, headers only).  Returns the byte count (0 on failure).
+extern "C" JXLFILETYPEIO_API size_t jxlhip_selftest_headers(uint32_t xsize, uint32_t ysize, int32_t gray, int32_t alpha, int32_t lossless,
+                                                            uint32_t epf_iters, uint32_t sec_bytes, uint8_t* dst, size_t capacity) {
+  try {
+    EncImageInfo ii;
+    ii.xsize = xsize; ii.ysize = ysize; ii.gray = gray != 0; ii.alpha = alpha != 0; ii.xyb = !lossless;
+    EncFrameInfo fi;
+    fi.encoding = lossless ? 1 : 0;
+    fi.gab = !lossless; fi.epf_iters = lossless ? 0 : epf_iters;
+    BitWriter cs;
+    WriteCodestreamHeaders(ii, cs);
+    WriteFrameHeader(ii, fi, cs);
+    const uint32_t ng = ((xsize + 255) / 256) * ((ysize + 255) / 256), nlf = ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048);
+    std::vector<uint32_t> sizes(ng == 1 ? 1 : 2 + nlf + ng, sec_bytes);
+    WriteToc(sizes, cs);
+    std::vector<uint8_t> bytes = cs.Finish();
+    bytes.resize(bytes.size() + (size_t)sec_bytes * sizes.size(), 0);
+    std::vector<uint8_t> file = WriteContainer(bytes, nullptr, 0, nullptr, 0);
+    if (file.size() > capacity) return 0;
+    memcpy(dst, file.data(), file.size());
+    return file.size();
+  } catch (...) {
+    return 0;
+  }
+}

@@ -157,3 +157,22 @@ def test_encoder_tree_reads_back(nlf):
     import ctypes as C
     err = api.ErrorInfo()
     assert _selftests().jxlhip_selftest_tree(nlf, C.byref(err)) == 0, err.errorMessage
+
+
+@pytest.mark.parametrize("w,h,gray,alpha,lossless,epf", [(300, 280, 0, 1, 0, 1), (3840, 2160, 0, 1, 0, 2), (200, 120, 1, 0, 0, 0), (64, 64, 0, 0, 0, 3),
+                                                       (777, 531, 0, 1, 1, 0), (2049, 2049, 1, 1, 0, 1), (8, 8, 0, 0, 1, 0), (16384, 16384, 0, 1, 0, 1)])
+def test_encoder_headers_read_back(w, h, gray, alpha, lossless, epf):
+    """WriteCodestreamHeaders + WriteFrameHeader + WriteToc + WriteContainer (host_write.cc) -> ParseFile (host_parse.cc): geometry,
+    channel layout, loop-filter settings and the section table survive the trip."""
+    L = api.lib()
+    L.jxlhip_selftest_headers.restype = C.c_size_t
+    L.jxlhip_selftest_headers.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
+    buf = (C.c_uint8 * (1 << 22))()
+    n = L.jxlhip_selftest_headers(w, h, gray, alpha, lossless, epf, 3, buf, len(buf))
+    assert n > 0
+    info = api.peek(bytes(buf[:n]))
+    assert (info.width, info.height) == (w, h)
+    assert info.num_channels == (1 if gray else 3) + alpha and info.has_alpha == alpha
+    assert info.num_groups == ((w + 255) // 256) * ((h + 255) // 256)
+    assert info.num_lf_groups == ((w + 2047) // 2048) * ((h + 2047) // 2048)
+    assert info.gaborish == (0 if lossless else 1) and info.epf_iters == (0 if lossless else epf)

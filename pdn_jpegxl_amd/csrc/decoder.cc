@@ -341,6 +341,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   };
   std::vector<PerImg> L((size_t)n);
   int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
+  // Modular frames whose MA tree looks at decoded neighbours take the generic per-lane path: give it LDS row buffers (groups of up to
+  // 256 columns); with the weighted predictor its per-sample state goes to LDS as well, which limits a workgroup to 8 sections
+  int mod_lanes = 64, mod_rb = 0, mod_wp_lds = 0;
+  for (int i = 0; i < n; i++) {
+    if (parse_status[i] != DecoderStatus_Ok || frames[i].encoding != 1) continue;
+    if (!frames[i].tree_row_static && frames[i].group_dim <= 256) mod_rb = 256;
+    if (frames[i].tree_uses_wp && frames[i].group_dim <= 256) { mod_wp_lds = 1; mod_lanes = 8; }
+  }
+  if (!mod_rb) { mod_wp_lds = 0; mod_lanes = 64; }
   size_t chunk_pix = 0;   // padded pixels of the largest VarDCT frame of the batch
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
@@ -363,7 +372,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       l.mod_chan = blob.Take(sizeof(ModChanDev) * f.mod_coded.size());
       l.mod_desc = ws.Take(nsec * f.mod_coded.size() * sizeof(ChanDesc));
       if (f.tree_uses_wp) l.wp_grp = ws.Take(nsec * 10 * (f.group_dim + 2) * 4);
-      n_mod_tasks += f.single ? 1 : ((int)nsec + 63) / 64;
+      n_mod_tasks += f.single ? 1 : ((int)nsec + mod_lanes - 1) / mod_lanes;
       continue;
     }
     l.a_cmap = blob.Take(f.acode.ctx_map.size());
@@ -561,13 +570,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       status_off[i] = l.z_status;
       d.out = dev_out[i];
       auto code_lds_m = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-      lds_mod = std::max(lds_mod, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
+      lds_mod = std::max(lds_mod, 64 * 128 + (size_t)mod_lanes * mod_rb * 4 + (mod_wp_lds ? (size_t)mod_lanes * 10 * (mod_rb + 2) * 4 : 0) + 16 +
+                                      sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
       const uint32_t nsec = 1 + f.nlf + f.ng;
       max_mod_groups = std::max<int>(max_mod_groups, (int)nsec);
       max_mod_coded = std::max<int>(max_mod_coded, (int)f.mod_coded.size());
       max_mod_pixels = std::max(max_mod_pixels, (size_t)f.xsize * f.ysize);
       if (f.single) mod_tasks[nmod_t++] = SectionTask{i, 0, 1, 0};   // one bit stream: one lane walks all three sections
-      else for (uint32_t g = 0; g < nsec; g += 64) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, nsec - g), 0};
+      else for (uint32_t g = 0; g < nsec; g += mod_lanes) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(mod_lanes, nsec - g), 0};
       continue;
     }
     code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
@@ -733,7 +743,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
     LaunchModularAns(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
-                     max_mod_coded, stream);
+                     max_mod_coded, mod_lanes, mod_rb, mod_wp_lds, stream);
     for (auto& op : mod_ops) LaunchModularOp(op.kind, op.a, op.b, op.c, op.aw, op.ah, op.rw, op.rh, op.type, stream);
     LaunchModularOut(d_imgs, n, max_mod_pixels, stream);
     Mark("modular", stream, 2);

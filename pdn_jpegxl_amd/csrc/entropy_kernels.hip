@@ -261,15 +261,15 @@ __device__ __forceinline__ void LeafRow(LaneBits& b, uint32_t& state, const Code
 // Per-channel state in a lane-private global scratch: the true error and the four sub-predictor errors of the current
 // and the previous row ((w + 2) entries each), exactly as the format defines them.
 struct WpState {
-  JXL_GLB int32_t* err;        // [2][w + 2]
-  JXL_GLB uint32_t* pe;        // [4][2][w + 2]
+  int32_t* err;                // [2][w + 2]   (generic pointers: the scratch is LDS when it fits, global memory otherwise)
+  uint32_t* pe;                // [4][2][w + 2]
   int w2;                      // w + 2
   int64_t prediction[4];
   int64_t pred;
   __device__ void Init(int32_t* scratch, int w) {
     w2 = w + 2;
-    err = G(scratch);
-    pe = (JXL_GLB uint32_t*)(err + 2 * w2);
+    err = scratch;
+    pe = (uint32_t*)(err + 2 * w2);
     for (int i = 0; i < 10 * w2; i++) err[i] = 0;
   }
   static __device__ __forceinline__ uint32_t Div(uint32_t i) { return (1u << 24) / (i + 1); }
@@ -285,7 +285,7 @@ struct WpState {
     const uint32_t kW[4] = {13, 12, 12, 12};
     uint32_t weights[4];
     for (int i = 0; i < 4; i++) {
-      const JXL_GLB uint32_t* p = pe + (size_t)i * 2 * w2;
+      const uint32_t* p = pe + (size_t)i * 2 * w2;
       weights[i] = ErrorWeight((uint64_t)p[pN] + p[pNE] + p[pNW], kW[i]);
     }
     N <<= 3; W <<= 3; NE <<= 3; NW <<= 3; NN <<= 3;
@@ -318,7 +318,7 @@ struct WpState {
     err[cur + x] = (int32_t)(pred - val);
     for (int i = 0; i < 4; i++) {
       const uint32_t e = (uint32_t)((Abs(prediction[i] - val) + 3) >> 3);
-      JXL_GLB uint32_t* p = pe + (size_t)i * 2 * w2;
+      uint32_t* p = pe + (size_t)i * 2 * w2;
       p[cur + x] = e;
       p[prev + x + 1] += e;
     }
@@ -516,7 +516,8 @@ __device__ int ClassifyChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree
 // Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
 template <bool kLds>
 __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
-                                  int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr) {
+                                  int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr,
+                                  const RowBuf<kLds>* lane_rows = nullptr) {
   ChanDesc d;
   d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
   if (w <= 0 || h <= 0) { *desc = d; return; }
@@ -528,6 +529,7 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
   if (cls == 0) {
     RowBuf<kLds> rbuf;
     rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
+    if (lane_rows) rbuf = *lane_rows;   // previous row in LDS instead of re-reading the plane (store -> load round trips)
     ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf, wp_scratch);
     *desc = d;
     return;
@@ -1271,14 +1273,24 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // Phase A: one lane per section.  A frame with a single TOC entry is one bit stream: its lane walks global, LF group and pass
 // group one after the other.
 template <bool kLds>
-__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks) {
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
+  // LDS: bit windows | previous-row buffers (rb_width ints per lane, interleaved) | weighted-predictor state | tree + code
+  const size_t off_rows = (size_t)64 * kRingWords * 4;
+  const size_t off_wp = off_rows + (size_t)lanes * rb_width * 4;
+  const size_t wp_ints = (size_t)10 * (rb_width + 2);
+  const size_t off_tab = off_wp + (wp_lds ? (size_t)lanes * wp_ints * 4 : 0);
   ModTables<kLds> mt;
-  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64);
   const int lane = threadIdx.x;
-  if (lane >= task.count) return;
+  if (lane >= task.count || lane >= lanes) return;
+  RowBuf<kLds> rows;
+  rows.rb = (typename AS<kLds>::Row)((JXL_LDS int32_t*)((JXL_LDS uint8_t*)smem + off_rows) + lane);
+  rows.rb_stride = lanes;
+  rows.rb_width = rb_width;
+  int32_t* const wp_local = wp_lds ? (int32_t*)(smem + off_wp) + (size_t)lane * wp_ints : nullptr;
   const int s0 = task.first + lane;
   const int nsub = im.single ? 3 : 1;   // single: this lane continues through sections 0, 1, 2
   LaneBits b;
@@ -1312,7 +1324,8 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
       const ModChanDev ch = im.mod_chan[c];
       ModRect r;
       if (!ModSectionRect(im, kind, g, ch, c, &r)) continue;
-      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, sub, sid, r.w, r.h, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, desc + c, wps);
+      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, sub, sid, r.w, r.h, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, desc + c,
+                              (wps && wp_local && r.w <= rb_width) ? wp_local : wps, rb_width ? &rows : nullptr);
       sub++;
     }
     if (state != 0x130000u) err |= kErrBitstream;
@@ -1498,13 +1511,15 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
 }
 
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      hipStream_t s) {
+                      int lanes, int rb_width, int wp_lds, hipStream_t s) {
   if (ntasks <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks);
+    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds);
   } else {
-    hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), 64 * kRingWords * 4, s, imgs, tasks);
+    const size_t lds = (size_t)64 * kRingWords * 4 + (size_t)lanes * rb_width * 4 + (wp_lds ? (size_t)lanes * 10 * (rb_width + 2) * 4 : 0);
+    RaiseLds((const void*)modular_ans_kernel<false>, lds);
+    hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), lds, s, imgs, tasks, lanes, rb_width, wp_lds);
   }
   hipLaunchKernelGGL(modular_finish_kernel, dim3(max_sections * max_coded, nimg), dim3(64), 0, s, imgs, max_coded);
 }

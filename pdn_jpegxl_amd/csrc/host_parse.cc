@@ -667,6 +667,7 @@ void ReadTree(Bits& r, ParsedFrame& f, size_t limit) {
   ReadCode(r, 6, c);
   SymReader sr(c, r);
   f.tree.clear();
+  f.tree_row_static = true;
   size_t pending = 1, leaves = 0;
   while (pending--) {
     REQUIRE(f.tree.size() < limit, "MA tree too large");
@@ -688,12 +689,14 @@ void ReadTree(Bits& r, ParsedFrame& f, size_t limit) {
       n.b = (mb + 1) << ml;
       leaves++;
       if (pred == 6) f.tree_uses_wp = true;
+      if (!(pred == 0 || pred == 1 || pred == 2 || pred == 5)) f.tree_row_static = false;
     } else {
       n.splitval = (int32_t)Unpack(sr.Get(0));
       n.a = (uint32_t)(f.tree.size() + pending + 1);
       n.b = (uint32_t)(f.tree.size() + pending + 2);
       pending += 2;
       if (prop == 15) f.tree_uses_wp = true;
+      if (prop > 2) f.tree_row_static = false;
       if (prop > 15) f.tree_uses_ref = true;
     }
     f.tree.push_back(n);

@@ -96,6 +96,7 @@ struct ParsedFrame {
   bool has_global_tree = false;
   std::vector<DevTreeNode> tree;
   bool tree_uses_wp = false, tree_uses_ref = false;
+  bool tree_row_static = true;   // every inner node tests channel / stream / row only and every leaf predicts Zero / W / N / Gradient
   HostCode mcode;
   bool global_modular_has_channels = false;
   // Modular frames (encoding 1): the GlobalModular image header

@@ -16,8 +16,10 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical
 // unsqueeze of planes a (average), b (residual) into c); clamp + interleave
+// lanes: sections per workgroup; rb_width > 0: previous-row buffers (and, with wp_lds, the weighted-predictor state) of the generic
+// lane path live in LDS
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      hipStream_t s);
+                      int lanes, int rb_width, int wp_lds, hipStream_t s);
 void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
 void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
 // kernels.hip

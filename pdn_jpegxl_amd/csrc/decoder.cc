@@ -118,6 +118,7 @@ struct JxlHipDecoder {
   int sticky_status = 0;
   // options
   int lane_stride_override = 0;
+  int hf_ring_override = 0;
   bool debug_taps = false;
   // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
   int band_first_row = 0, band_rows = 0;
@@ -141,9 +142,13 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   if (dev < 0) HIP_OK(hipGetDevice(&dev));
   device = dev;
   HIP_OK(hipSetDevice(device));
-  HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&stream_lf, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&stream_hf, hipStreamNonBlocking));
+  int prio_lo = 0, prio_hi = 0;
+  HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+  const char* pe = getenv("JXLHIP_PIX_PRIO");
+  const int pmode = pe ? atoi(pe) : 0;   // experiment: 1 = pixel stream at the highest priority, 2 = entropy streams at the highest
+  HIP_OK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, pmode == 1 ? prio_hi : (pmode == 2 ? prio_lo : 0)));
+  HIP_OK(hipStreamCreateWithPriority(&stream_lf, hipStreamNonBlocking, pmode == 2 ? prio_hi : (pmode == 1 ? prio_lo : 0)));
+  HIP_OK(hipStreamCreateWithPriority(&stream_hf, hipStreamNonBlocking, pmode == 2 ? prio_hi : (pmode == 1 ? prio_lo : 0)));
   for (auto& S : slots) {
     HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));
@@ -179,6 +184,7 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     dq_n[q] = (uint32_t)(st.dq[q].size() / 3);
   }
   if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
+  if (const char* e = getenv("JXLHIP_HF_RING")) hf_ring_override = atoi(e);
 }
 
 JxlHipDecoder::~JxlHipDecoder() {
@@ -472,6 +478,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   imgs.assign(n, DevImage());
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_lf = 0, lds_alpha = 0;
+  int hf_slots = 0;   // lanes the HF kernel's LDS arrays are laid out for: the largest section count of a workgroup
   bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
@@ -673,7 +680,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-    lds_hf = std::max(lds_hf, (size_t)per_wg * (96 + 64 + 128) + code_lds(f.acode) + 2 + 8448 * 2 + 64);
+    lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64 + 32);   // tables; the per-lane part is added below
     lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = lds_lf;
     max_groups = std::max<int>(max_groups, (int)f.ng);
@@ -685,7 +692,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (uint32_t g = l0; g < l1; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, l1 - g), 0};
     }
     const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
-    for (uint32_t g = hg0; g < hg1; g += per_wg) pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, hg1 - g), 0};
+    for (uint32_t g = hg0; g < hg1; g += per_wg) {
+      pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, hg1 - g), 0};
+      hf_slots = std::max<int>(hf_slots, (int)std::min<uint32_t>(per_wg, hg1 - g));
+    }
     const uint32_t ag0 = (uint32_t)(d.band_y0 / kGroupDim) * f.xg, ag1 = (uint32_t)((d.band_y1 + kGroupDim - 1) / kGroupDim) * f.xg;
     if (d.has_alpha)
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
@@ -713,8 +723,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
   Mark("hf_start", s_hf, 1);
-  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, lds_hf <= kLdsMax ? lds_hf : 0, d_natural_small,
-                 s_hf);
+  // More workgroups than CUs: the narrow bit window (192 B of LDS per lane instead of 288) lets two of them share a CU, so the
+  // launch is resident in one round and leaves whole CUs to the concurrent pixel stages.
+  hf_slots = (hf_slots + 3) & ~3;
+  int hf_ring = npass_t > 256 ? 16 : 32;
+  if (hf_ring_override == 16 || hf_ring_override == 32) hf_ring = hf_ring_override;
+  lds_hf += (size_t)hf_slots * HfLaneLdsBytes(hf_ring);
+  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0,
+                 d_natural_small, s_hf);
   Mark("hf_decode", s_hf, 1);
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages

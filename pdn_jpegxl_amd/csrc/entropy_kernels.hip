@@ -51,7 +51,8 @@ typedef unsigned __attribute__((ext_vector_type(4))) U4;   // one MA-tree node (
 // 48 bits, so 24 words), which is the only place that waits on global memory.
 constexpr int kRingWords = 32;
 constexpr int kTopUpEvery = 16;
-struct LaneBits {
+template <int kRing, int kBatch>
+struct LaneBitsT {
   const JXL_GLB uint32_t* w;   // 32-byte aligned base of the lane's stream
   JXL_LDS uint32_t* ring;
   uint32_t rs;                 // ring stride (slots)
@@ -60,21 +61,26 @@ struct LaneBits {
   uint64_t buf;
   int n;
   int skip;
-  __device__ __forceinline__ void Batch() {   // stages words [filled, filled + 8)
-    uint32_t v[8];
-    if (filled + 8 <= nwords) {
-      const U4 a = *(const JXL_GLB U4*)(w + filled), c = *(const JXL_GLB U4*)(w + filled + 4);
-      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+  __device__ __forceinline__ void Batch() {   // stages words [filled, filled + kBatch)
+    static_assert(kBatch == 4 || kBatch == 8, "one or two 16-byte loads");
+    uint32_t v[kBatch];
+    if (filled + kBatch <= nwords) {
+      const U4 a = *(const JXL_GLB U4*)(w + filled);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      if constexpr (kBatch == 8) {
+        const U4 c = *(const JXL_GLB U4*)(w + filled + 4);
+        v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = filled + i < nwords ? w[filled + i] : 0u;
+      for (int i = 0; i < kBatch; i++) v[i] = filled + i < nwords ? w[filled + i] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) ring[((filled + i) & (kRingWords - 1)) * rs] = v[i];
-    filled += 8;
+    for (int i = 0; i < kBatch; i++) ring[((filled + i) & (kRing - 1)) * rs] = v[i];
+    filled += kBatch;
   }
   __device__ __forceinline__ void TopUp() {
-    while (filled + 8 <= rd + kRingWords) Batch();
+    while (filled + kBatch <= rd + kRing) Batch();
   }
   __device__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off, JXL_LDS uint32_t* ring_slot, uint32_t ring_stride) {
     const uintptr_t addr = (uintptr_t)cs + (bit_off >> 3);
@@ -94,7 +100,7 @@ struct LaneBits {
   }
   __device__ __forceinline__ void Refill() {
     if (n <= 32) {
-      buf |= (uint64_t)ring[(rd & (kRingWords - 1)) * rs] << n;
+      buf |= (uint64_t)ring[(rd & (kRing - 1)) * rs] << n;
       n += 32;
       rd++;
     }
@@ -109,6 +115,8 @@ struct LaneBits {
   // bits consumed since Init (relative to the bit offset given to Init)
   __device__ uint64_t Consumed() const { return (uint64_t)rd * 32 - n - skip; }
 };
+// the default window: 32 words, topped up (two 16-byte loads at a time) every 16 tokens
+typedef LaneBitsT<kRingWords, 8> LaneBits;
 
 template <bool kLds> struct AS;
 template <> struct AS<true> {
@@ -142,7 +150,8 @@ __device__ __forceinline__ DevTreeNode NodeOf(I4 v) {
   return n;
 }
 
-__device__ __forceinline__ uint32_t HybridTail(LaneBits& b, uint32_t c, uint32_t sym) {
+template <class Bits>
+__device__ __forceinline__ uint32_t HybridTail(Bits& b, uint32_t c, uint32_t sym) {
   const uint32_t se = c & 0xF, split = 1u << se;
   if (sym < split) return sym;
   const uint32_t msb = (c >> 4) & 0xF, lsb = (c >> 8) & 0xF;
@@ -170,8 +179,8 @@ __device__ __forceinline__ uint32_t AnsSym(LaneBits& b, uint32_t& state, typenam
   return sym;
 }
 
-template <bool kLds>
-__device__ __forceinline__ uint32_t AnsGet(LaneBits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
+template <bool kLds, class Bits>
+__device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
   const uint32_t cl = t.cmap[ctx];
   const uint32_t le = 12 - t.log_alpha;
   const uint32_t res = state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
@@ -959,26 +968,32 @@ __device__ __noinline__ void StoreViaGlobalOrder(const uint16_t* order, uint32_t
 // iteration: the number-of-nonzeros token of a (block, channel) or one coefficient token.  Per-lane state that the
 // context model needs (non-zero counts of the row above / the cell to the left) is a 32-entry column buffer per
 // channel in LDS: col[x] = value of the last decoded block covering column x, which is both "above" and "left".
-template <bool kLds>
-__global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride,
+// kRing: words of the per-lane bit window.  32 (top-up every 16 tokens, 8 queued descriptors: 288 B of LDS per lane) is the
+// faster loop for one frame; 16 (top-up every 8 tokens, 4 descriptors: 192 B per lane) lets two workgroups share a CU, which is
+// what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
+// (>= the largest task.count of the launch).
+template <bool kLds, int kRing>
+__global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots,
                                                         const uint16_t* natural_orders_small) {
+  constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
+  constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
+  typedef LaneBitsT<kRing, kRing / 4> Bits;
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   const int per_wave = 64 / lane_stride;
-  const int nslots = 4 * per_wave;
   CodeTab<kLds> tab;
   typename AS<kLds>::U16 lds_orders;
   typename AS<kLds>::U8 nnz_tab;
   typename AS<kLds>::U16 order_off;
   JXL_LDS uint8_t* nzcol;
   JXL_LDS uint32_t* ring_base;
-  JXL_LDS U2* descq;   // per lane: queue of the next 8 varblock descriptors, entry j at descq[(j & 7) * nslots + slot]
+  JXL_LDS U2* descq;   // per lane: queue of the next kQ varblock descriptors, entry j at descq[(j & (kQ - 1)) * nslots + slot]
   {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     size_t off = 0;
-    ring_base = (JXL_LDS uint32_t*)lds; off += (size_t)nslots * kRingWords * 4;
-    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * 8 * 8;
+    ring_base = (JXL_LDS uint32_t*)lds; off += (size_t)nslots * kRing * 4;
+    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * kQ * 8;
     nzcol = lds + off; off += (size_t)nslots * 96;
     if constexpr (kLds) {
       off = StageCode(lds, off, im.acode, tab, threadIdx.x, blockDim.x);
@@ -1004,12 +1019,12 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   // each vector instruction in one pass instead of two.
   if ((int)(threadIdx.x & 63) >= per_wave) return;
   const int si = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
-  if (si >= task.count) return;
+  if (si >= task.count || si >= nslots) return;
   JXL_LDS uint8_t* const col = nzcol + si;   // col[(c * 32 + x) * nslots]
   const int g = task.first + si;
   const int sec = im.single ? 0 : 2 + im.nlf + g;
   const uint64_t sec_bits = im.single ? im.hf_start_bits : im.sec_off[sec] * 8;
-  LaneBits b;
+  Bits b;
   b.Init(im.cs, im.cs_size, sec_bits, ring_base + si, (uint32_t)nslots);
   const uint32_t preset = b.Read(CeilLog2D((uint32_t)im.num_presets));
   const uint32_t nbc = im.num_block_ctx;
@@ -1042,16 +1057,15 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
   JXL_GLB int32_t* const coef2 = G(im.coef[2]);
   bool want_nz = true;
   while (!err) {
-    if ((it & (kTopUpEvery - 1)) == 0) {
-      // a token consumes at most 48 bits and starts at most one block: 16 tokens never outrun 24 words / 6 descriptors
+    if ((it & (kTop - 1)) == 0) {
       b.TopUp();
-      const uint32_t lim = min(nblk, bi + 8);
+      const uint32_t lim = min(nblk, bi + kQ);
       if (dfilled < lim) {
-        U2 v[8];
+        U2 v[kQ];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
+        for (int i = 0; i < kQ; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
 #pragma unroll
-        for (int i = 0; i < 8; i++) if (dfilled + i < lim) dq[(size_t)((dfilled + i) & 7) * nslots] = v[i];
+        for (int i = 0; i < kQ; i++) if (dfilled + i < lim) dq[(size_t)((dfilled + i) & (kQ - 1)) * nslots] = v[i];
         dfilled = lim;
       }
     }
@@ -1083,13 +1097,13 @@ __global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, co
           prev = 0;
         }
         if (++k >= size && nzeros != 0) { err |= kErrBitstream; leave = true; }
-        if (__any(leave) || (it & (kTopUpEvery - 1)) == 0) break;
+        if (__any(leave) || (it & (kTop - 1)) == 0) break;
       }
       continue;
     }
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
-      const U2 d = dq[(size_t)(bi & 7) * nslots];
+      const U2 d = dq[(size_t)(bi & (kQ - 1)) * nslots];
       bi++;
       bx = d.x & 31; by = (d.x >> 5) & 31;
       const uint32_t s = (d.x >> 10) & 31;
@@ -1488,15 +1502,23 @@ void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream
   hipLaunchKernelGGL(hf_blocklist_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 
-void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes,
+size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 4) * 8; }
+
+void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
                     const uint16_t* natural_orders_small, hipStream_t s) {
   if (nwg <= 0) return;
-  const size_t col_bytes = (size_t)(4 * (64 / lane_stride)) * (96 + 64 + kRingWords * 4);
+  const size_t lane_bytes = (size_t)nslots * HfLaneLdsBytes(32);   // tables in global memory: always the wide window
   if (lds_bytes) {
-    RaiseLds((const void*)hf_decode_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(hf_decode_kernel<true>, dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, natural_orders_small);
+    if (ring_words == 16) {
+      RaiseLds((const void*)hf_decode_kernel<true, 16>, lds_bytes);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+    } else {
+      RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+    }
   } else {
-    hipLaunchKernelGGL(hf_decode_kernel<false>, dim3(nwg), dim3(256), col_bytes, s, imgs, tasks, lane_stride, natural_orders_small);
+    RaiseLds((const void*)hf_decode_kernel<false, 32>, lane_bytes);
+    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(256), lane_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
   }
 }
 

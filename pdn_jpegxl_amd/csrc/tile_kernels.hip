@@ -59,18 +59,18 @@ __device__ __forceinline__ uint8_t ToU8T(float v) {
   return (uint8_t)(v + 0.5f);
 }
 
-__device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, float X, float Y, float B) {
+// `a`: the pixel's alpha sample (ignored by layouts without alpha), fetched by the caller ahead of the arithmetic
+__device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, float X, float Y, float B, uint8_t a) {
   const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
   const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
   float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
   float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
   if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
-  const size_t i = (size_t)y * im.w + x;                       // position in the frame (alpha plane)
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.nch_out == 4) {
     uchar4 px;
-    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = im.alpha[i];
+    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = a;
     ((uchar4*)im.out)[o] = px;
   } else {
     uint8_t* out = im.out + o * im.nch_out;
@@ -78,9 +78,12 @@ __device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, flo
       out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
     } else {
       out[0] = ToU8T(g);
-      if (im.has_alpha) out[1] = im.alpha[i];
+      if (im.has_alpha) out[1] = a;
     }
   }
+}
+__device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, float X, float Y, float B) {
+  WritePixelA(im, x, y, X, Y, B, im.has_alpha ? im.alpha[(size_t)y * im.w + x] : (uint8_t)255);
 }
 
 }  // namespace
@@ -350,6 +353,291 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
   }
 }
 
+// ------------------------------------------------------------------ fused reconstruction, one LDS tile, three barriers
+// Same arithmetic as recon_tile_kernel (same fma chains, same order) with the phases reorganised around what the
+// profile showed (two thirds of the wave time parked at barriers / on memory):
+//   * one 64x65 tile: both IDCT passes run IN PLACE.  The vertical pass gives wavefront w the column stripe [16w, 16w+16)
+//     (everything a stripe's outputs depend on lies in the same columns), the horizontal pass gives it the row band
+//     [16w, 16w+16); a wavefront fetches all its operands before it stores, so no workgroup barrier is needed inside a
+//     pass, and the copy-out of a row band needs only that wavefront.  LDS 19 KB -> 6 workgroups per CU (VGPR-bound).
+//   * LLF is computed by wavefront 0 with lane shuffles (no LDS staging, no barriers) while the others dequantise; the
+//     dequantisation skips the LLF positions instead of being overwritten after a barrier.
+//   * dequantisation: one thread = four consecutive coefficients of a row (one 16-byte load per plane and per weight
+//     table), per-cell constants (table pointer with the block offset folded in, scale, index shift) prepared once.
+//   * 1 / v through v_rcp_f32 (1 ulp; the term is a bias correction <= 0.15 / |v|).
+__device__ __forceinline__ float DequantBias(int32_t v, float qb, float qb3) {
+  if (v == 0) return 0.f;
+  if (v == 1) return qb;
+  if (v == -1) return -qb;
+  const float f = (float)v;
+  return f - qb3 * __builtin_amdgcn_rcpf(f);
+}
+typedef int __attribute__((ext_vector_type(4))) I4v;
+
+__global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
+                                                             const float* llf_scale) {
+  extern __shared__ __align__(16) uint8_t smem_raw[];
+  float* cfc = (float*)smem_raw;                       // kTS * kLP   coefficients -> columns done -> pixels
+  float* B816 = cfc + kTS * kLP;                       // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
+  float* cscale = B816 + 320;                          // 64   per cell: inv_global_scale / raw quant of its varblock
+  uint32_t* ci = (uint32_t*)(cscale + 64);             // 64   cell info
+  uint32_t* cmeta = ci + 64;                           // 64   log2 of the table pitch | transposed << 4 | origin cell: 1 << 16 | lcx << 8 | lcy << 12
+  uint32_t* cnq = cmeta + 64;                          // 64   entries per channel of the cell's dequant table
+  const float** cw = (const float**)(cnq + 64);        // 64   table base + offset of the cell inside its varblock
+  const DevImage& im = imgs[blockIdx.y];
+  const int tile = blockIdx.x / 3, cidx = blockIdx.x % 3;
+  if (tile >= im.wt * im.ht) return;
+  const int tid = threadIdx.x;
+  const int tx = tile % im.wt, ty = tile / im.wt;
+  if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
+  const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
+  int bad = 0;
+  uint32_t info0 = 0;
+  float lfv = 0.f;
+  if (tid < 64) {
+    const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
+    const bool inside = cx < im.w8 && cy < im.h8;
+    const size_t cell_g = (size_t)min(cy, im.h8 - 1) * im.w8 + min(cx, im.w8 - 1);
+    const uint32_t info_g = im.cellinfo[cell_g];
+    const uint32_t rq_g = im.rawq[cell_g];
+    const float lf_g = im.lf_final[c][cell_g];
+    const uint32_t info = inside ? info_g : 0u;
+    const uint32_t rqv = inside ? rq_g : 1u;
+    lfv = inside ? lf_g : 0.f;
+    info0 = info;
+    const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+    if (inside) {
+      if (!(info >> 31)) bad = 1;
+      else {
+        const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
+        // blocks larger than the tile, and the rare special 8x8 transforms, are left to the generic kernels
+        bad = ox < 0 || oy < 0 || ox + (1 << lcx) > 8 || oy + (1 << lcy) > 8 || Special(info & 0xFF);
+      }
+    }
+    const bool valid = (info >> 31) && !bad;
+    const uint32_t q = t_quant_table[valid ? (info & 0xFF) : 0];
+    const uint32_t rq_origin = (uint32_t)__shfl((int)rqv, valid ? tid - iy * 8 - ix : tid);
+    const uint32_t lng = 3 + max(lcx, lcy);
+    const bool transposed = lcy > lcx;   // square DCT tables are symmetric: row-major walks give consecutive lanes consecutive weights
+    ci[tid] = info;
+    cscale[tid] = im.inv_global_scale / (float)rq_origin;
+    cmeta[tid] = lng | (transposed ? 16u : 0u) | ((valid && ix == 0 && iy == 0) ? (1u << 16) | ((uint32_t)lcx << 8) | ((uint32_t)lcy << 12) : 0u);
+    cnq[tid] = im.dq_n[q];
+    cw[tid] = im.dq[q] + (transposed ? ((uint32_t)(8 * ix) << lng) + 8 * iy : ((uint32_t)(8 * iy) << lng) + 8 * ix);
+  }
+  for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
+  if (__syncthreads_or(bad)) {
+    if (tid == 0 && cidx == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
+    return;
+  }
+  const int wp = im.wp, hp = im.hp;
+  const float* const Bl = basis_all;
+  // ---- LLF (wavefront 0): lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples, by lane shuffles
+  if (tid < 64) {
+    const uint32_t info = info0;
+    const bool valid = info >> 31;
+    const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+    const int cx = 1 << lcx, cy = 1 << lcy;
+    const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
+    const float* Bx = basis_small + (cx * cx - 1) / 3 + ix * cx;
+    const float* By = basis_small + (cy * cy - 1) / 3 + iy * cy;
+    float bx[8], byv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { bx[k] = (valid && k < cx) ? Bx[k] : 0.f; byv[k] = (valid && k < cy) ? By[k] : 0.f; }
+    const float sc = valid ? llf_scale[lcy * 32 + iy] * llf_scale[lcx * 32 + ix] / (float)(cx * cy) : 0.f;
+    float row = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float v = __shfl(lfv, (tid - ix + k) & 63);
+      if (valid && k < cx) row += v * bx[k];
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const float v = __shfl(row, ((oy + k) * 8 + (tid & 7)) & 63);
+      if (valid && k < cy) acc += v * byv[k];
+    }
+    if (valid) cfc[(oy * 8 + iy) * kLP + ox * 8 + ix] = acc * sc;
+  }
+  // ---- dequantisation (+ chroma from luma)
+  {
+    const size_t tile_cfl = (size_t)ty * im.wt + tx;
+    const float cfl = c == 1 ? 0.f : (c == 0 ? im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor
+                                              : im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor);
+    const float qbc = im.qbias[c], qb1 = im.qbias[1], qb3 = im.qbias[3];
+    const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
+    const int32_t* qc = im.coef[c];
+    const int32_t* qy = im.coef[1];
+    const int x4 = (tid & 15) * 4, yb = tid >> 4;
+    const int gx = tx * kTS + x4;
+    const int xx = x4 & 7, ccol = x4 >> 3;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int y = yb + 16 * it;
+      const int gy = ty * kTS + y;
+      const bool inside = gx < wp && gy < hp;
+      const int cell = (y >> 3) * 8 + ccol;
+      const uint32_t meta = cmeta[cell];
+      const uint32_t nq = cnq[cell];
+      const float* wt = cw[cell];
+      const float scale = cscale[cell];
+      const uint32_t lng = meta & 15;
+      const bool transposed = meta & 16;
+      const int yy = y & 7;
+      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 4);
+      const I4v v = *(const I4v*)(qc + g);
+      float w[4], wy[4];
+      I4v vy = {0, 0, 0, 0};
+      if (c != 1) vy = *(const I4v*)(qy + g);
+      if (!transposed) {
+        const uint32_t idx = ((uint32_t)yy << lng) + xx;
+        const float4 t = *(const float4*)(wt + (size_t)c * nq + idx);
+        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
+        if (c != 1) { const float4 u = *(const float4*)(wt + (size_t)nq + idx); wy[0] = u.x; wy[1] = u.y; wy[2] = u.z; wy[3] = u.w; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t idx = ((uint32_t)(xx + j) << lng) + yy;
+          w[j] = wt[(size_t)c * nq + idx];
+          if (c != 1) wy[j] = wt[(size_t)nq + idx];
+        }
+      }
+      int nskip = 0;   // leading LLF positions of this group of four (written by wavefront 0)
+      if ((meta >> 16) & 1) {
+        const int cx = 1 << ((meta >> 8) & 7), cy = 1 << ((meta >> 12) & 7);
+        if (yy < cy) nskip = min(max(cx - xx, 0), 4);
+      }
+      const int vv[4] = {v.x, v.y, v.z, v.w}, vvy[4] = {vy.x, vy.y, vy.z, vy.w};
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float o = DequantBias(vv[j], qbc, qb3) * (scale * dm) * w[j];
+        if (c != 1) o += cfl * (DequantBias(vvy[j], qb1, qb3) * scale * wy[j]);
+        if (j >= nskip) cfc[y * kLP + x4 + j] = inside ? o : 0.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, l16 = tid & 15, lq = lane >> 4;
+  // ---- vertical pass, in place: wavefront = column stripe.  Matrix cores for every 16x16 sub-block that lies inside a varblock
+  // of at least 16 points both ways: Basis_R^T (16 x R) * coefficients (R x 16) by v_mfma_f32_16x16x4_f32 (exact f32, the same
+  // k-ordered fma chain as the VALU path).  Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], owns D[4 * (l >> 4) + r][l & 15].
+  {
+    F4 acc[4];
+    bool m[4];
+    const int x0 = wave * 16;
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++) {
+      const uint32_t inf = ci[rb * 16 + wave * 2];
+      m[rb] = MfmaSubBlock(inf);   // wave-uniform
+      if (m[rb]) {
+        const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
+        const float* B = (R == 16 ? B816 + 64 : Bl + (R * R - 64) / 3) + lq * R + iy * 8 + l16;
+        const float* cp = cfc + ((rb * 2 - iy) * 8 + lq) * kLP + x0 + l16;
+        acc[rb] = MfmaChainN(R, B, 4 * R, cp, 4 * kLP);
+      }
+    }
+    // the rest on the vector ALUs.  One lane = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
+    const int x = x0 + (lane & 7) * 2, cr = lane >> 3;
+    const uint32_t info = ci[cr * 8 + (x >> 3)];
+    const bool valu = (info >> 31) && !MfmaSubBlock(ci[(cr >> 1) * 16 + (x >> 4) * 2]);
+    float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valu) {
+      const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
+      const int R = 8 << lcy;
+      const float* in = cfc + (cr - iy) * 8 * kLP + x;
+      if (R == 8) {            // the common sizes read their basis from LDS: no global load inside the pass
+#pragma unroll 2
+        for (int k = 0; k < 8; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
+      } else if (R == 16) {
+        const float* B = B816 + 64 + iy * 8;
+#pragma unroll 2
+        for (int k = 0; k < 16; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
+      } else {
+        const float* B = Bl + (R * R - 64) / 3 + iy * 8;
+        for (int k = 0; k < R; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * R, v0, v1) }
+      }
+    }
+    // every operand of this stripe is in registers: store
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rb = 0; rb < 4; rb++)
+      if (m[rb]) {
+        float* o = cfc + (rb * 16 + 4 * lq) * kLP + x0 + l16;
+        o[0] = acc[rb].x; o[kLP] = acc[rb].y; o[2 * kLP] = acc[rb].z; o[3 * kLP] = acc[rb].w;
+      }
+    if (valu) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { cfc[(cr * 8 + j) * kLP + x] = a0[j]; cfc[(cr * 8 + j) * kLP + x + 1] = a1[j]; }
+    }
+  }
+  __syncthreads();
+  // ---- horizontal pass, in place: wavefront = row band: rows (16 x C) * Basis_C (C x 16)
+  {
+    F4 acc[4];
+    bool m[4];
+    const int y0 = wave * 16;
+#pragma unroll
+    for (int cs = 0; cs < 4; cs++) {
+      const uint32_t inf = ci[wave * 16 + cs * 2];
+      m[cs] = MfmaSubBlock(inf);
+      if (m[cs]) {
+        const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
+        const float* B = (C == 16 ? B816 + 64 : Bl + (C * C - 64) / 3) + lq * C + ix * 8 + l16;
+        const float* ap = cfc + (y0 + l16) * kLP + (cs * 2 - ix) * 8 + lq;
+        acc[cs] = MfmaChainN(C, ap, 4, B, 4 * C);
+      }
+    }
+    // the rest: two adjacent rows per lane
+    const int y = y0 + (lane & 7) * 2, cc = lane >> 3;
+    const uint32_t info = ci[(y >> 3) * 8 + cc];
+    const bool valu = (info >> 31) && !MfmaSubBlock(ci[(y >> 4) * 16 + (cc >> 1) * 2]);
+    float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (valu) {
+      const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
+      const int C = 8 << lcx;
+      const float* in = cfc + y * kLP + (cc - ix) * 8;
+      if (C == 8) {
+#pragma unroll 2
+        for (int k = 0; k < 8; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
+      } else if (C == 16) {
+        const float* B = B816 + 64 + ix * 8;
+#pragma unroll 2
+        for (int k = 0; k < 16; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
+      } else {
+        const float* B = Bl + (C * C - 64) / 3 + ix * 8;
+        for (int k = 0; k < C; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * C, v0, v1) }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int cs = 0; cs < 4; cs++)
+      if (m[cs]) {
+        float* o = cfc + (y0 + 4 * lq) * kLP + cs * 16 + l16;
+        o[0] = acc[cs].x; o[kLP] = acc[cs].y; o[2 * kLP] = acc[cs].z; o[3 * kLP] = acc[cs].w;
+      }
+    if (valu) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) { cfc[y * kLP + cc * 8 + j] = a0[j]; cfc[(y + 1) * kLP + cc * 8 + j] = a1[j]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- copy-out of this wavefront's row band: 16 bytes per lane
+    float* dst = im.xyb[c];
+    const int x4 = l16 * 4;
+    const int gx = tx * kTS + x4;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int yl = y0 + lq + 4 * it;
+      const int gy = ty * kTS + yl;
+      const float* r = cfc + yl * kLP + x4;
+      const float4 o = make_float4(r[0], r[1], r[2], r[3]);
+      if (gx < wp && gy < hp) *(float4*)(dst + (size_t)gy * wp + gx) = o;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ LDS-tiled loop filters
 // kStage: 0 Gaborish, 1 EPF pass 0, 2 EPF pass 1, 3 EPF pass 2.  Tile = 64 x 32 output pixels.
 template <int kStage>
@@ -468,17 +756,57 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
   const float* in0 = im.stage_in[0][0];
   const float* in1 = im.stage_in[0][1];
   const float* in2 = im.stage_in[0][2];
-  constexpr int kLoadIters = (IW * IH + 255) / 256;
+  // Everything the kernel reads from HBM is requested here, before the first barrier: the output phase's per-pixel operands
+  // (EPF sigma of the pixel's cell, alpha sample) used to be loaded where they are consumed, which parked every wavefront for
+  // a full memory round trip twice more per tile.  Output pixel of iteration `it`: (x0 + lxo, y0 + lyo + 8 * it).
+  const int lxo = threadIdx.x & 31, lyo = threadIdx.x >> 5;
+  float sig[4];
+  uint8_t al[4];
 #pragma unroll
-  for (int it = 0; it < kLoadIters; it++) {
-    const int e0 = threadIdx.x + it * 256;
-    const int e = e0 < IW * IH ? e0 : IW * IH - 1;
-    const int ly = e / IW, lx = e % IW;
-    const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
-    const float v0 = (ablate & 1) ? (float)lx : in0[g], v1 = (ablate & 1) ? (float)ly : in1[g], v2 = (ablate & 1) ? 0.5f : in2[g];
-    s_in[0][ly][lx] = v0;
-    s_in[1][ly][lx] = v1;
-    s_in[2][ly][lx] = v2;
+  for (int it = 0; it < 4; it++) {
+    const int xc = min(x0 + lxo, w - 1), yc = min(y0 + lyo + 8 * it, h - 1);
+    sig[it] = im.inv_sigma[(size_t)(yc >> 3) * im.w8 + (xc >> 3)];
+    al[it] = im.has_alpha ? im.alpha[(size_t)yc * w + xc] : (uint8_t)255;
+  }
+  if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h && !(ablate & 8)) {
+    // interior tile: no mirroring; rows [y0 - 3, y0 + 35) x columns [x0 - 4, x0 + 36) as aligned 16-byte loads
+    constexpr int kQ = (TW + 8) / 4;   // 10 quads per row
+    float4 q[2][3];
+    int qy[2], qx[2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int e0 = threadIdx.x + it * 256;
+      const int e = e0 < kQ * IH ? e0 : kQ * IH - 1;
+      qy[it] = e / kQ; qx[it] = e % kQ;
+      const size_t g = (size_t)(y0 - HI + qy[it]) * wp + (x0 - 4 + 4 * qx[it]);
+      q[it][0] = *(const float4*)(in0 + g);
+      q[it][1] = *(const float4*)(in1 + g);
+      q[it][2] = *(const float4*)(in2 + g);
+    }
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+      const int lx = 4 * qx[it] - 1;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        if (lx >= 0) s_in[c][qy[it]][lx] = q[it][c].x;
+        s_in[c][qy[it]][lx + 1] = q[it][c].y;
+        s_in[c][qy[it]][lx + 2] = q[it][c].z;
+        if (lx + 3 < IW) s_in[c][qy[it]][lx + 3] = q[it][c].w;
+      }
+    }
+  } else {
+    constexpr int kLoadIters = (IW * IH + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < kLoadIters; it++) {
+      const int e0 = threadIdx.x + it * 256;
+      const int e = e0 < IW * IH ? e0 : IW * IH - 1;
+      const int ly = e / IW, lx = e % IW;
+      const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
+      const float v0 = (ablate & 1) ? (float)lx : in0[g], v1 = (ablate & 1) ? (float)ly : in1[g], v2 = (ablate & 1) ? 0.5f : in2[g];
+      s_in[0][ly][lx] = v0;
+      s_in[1][ly][lx] = v1;
+      s_in[2][ly][lx] = v2;
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < GW * GH; e += 256) {
@@ -506,13 +834,13 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
       dv[gy][gx] = fabsf(t[0][gy][gx] - t[0][gy + 1][gx]) * cs0 + fabsf(t[1][gy][gx] - t[1][gy + 1][gx]) * cs1 + fabsf(t[2][gy][gx] - t[2][gy + 1][gx]) * cs2;
   }
   __syncthreads();
-#pragma unroll 2
-  for (int e = threadIdx.x; e < TW * TH; e += 256) {
-    const int ly = e / TW, lx = e % TW;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int ly = lyo + 8 * it, lx = lxo;
     const int x = x0 + lx, y = y0 + ly;
     if (x >= w || y < im.band_y0 || y >= im.band_y1) continue;
     const int cy = ly + HG, cx = lx + HG;
-    const float is = im.inv_sigma[(size_t)(y >> 3) * im.w8 + (x >> 3)];
+    const float is = sig[it];
     float o0 = t[0][cy][cx], o1 = t[1][cy][cx], o2 = t[2][cy][cx];
     if (!(is < -3.90524291751269967465540850526868f) && !(ablate & 2)) {
       const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
@@ -530,7 +858,7 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
       o2 = (o2 + w_u * t[2][cy - 1][cx] + w_l * t[2][cy][cx - 1] + w_r * t[2][cy][cx + 1] + w_d * t[2][cy + 1][cx]) * iw;
     }
     if (ablate & 4) { ((uchar4*)im.out)[(size_t)(y - im.band_y0) * im.w + x] = make_uchar4((uint8_t)(o0 * 255.f), (uint8_t)(o1 * 255.f), (uint8_t)(o2 * 255.f), 255); continue; }
-    WritePixel(im, x, y, o0, o1, o2);
+    WritePixelA(im, x, y, o0, o1, o2, al[it]);
   }
 }
 
@@ -559,6 +887,9 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
       raised = true;
     }
     hipLaunchKernelGGL(recon_tile_kernel<true>, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
+  } else if (!getenv("JXLHIP_RECON_OLD")) {
+    const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 4 + 128) * 4;
+    hipLaunchKernelGGL(recon_tile2_kernel, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale);
   } else {
     size_t lds = (size_t)(2 * kTS * kLP) * 4 + extra;
     if (getenv("JXLHIP_RECON_LDS")) lds = (size_t)atoi(getenv("JXLHIP_RECON_LDS"));

@@ -590,6 +590,21 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
 // Phase B: a wavefront applies the predictors of a row-static channel in place.  Lane r owns row y0 + r of a 64-row
 // batch, skewed by one sample per row: N comes from lane r-1's previous step (one DPP shuffle), NW is the lane's own
 // previous N, W its own previous value.  carry: LDS row (w ints, only used when h > 64) holding the batch's last row.
+// Value of `v` in the lane below (lane - 1), by a DPP wave shift (one VALU move; __shfl_up goes through the LDS crossbar,
+// and that round trip sat on the recurrence's critical path).  Lane 0 gets 0.  Call with all lanes active.
+__device__ __forceinline__ int32_t FromLaneBelow(int32_t v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
+// min(W, N) if NW >= max, max if NW <= min, else W + N - NW: the clamped gradient without 64-bit arithmetic (inside the
+// interval the sum cannot overflow).
+__device__ __forceinline__ int32_t ClampedGradient32(int32_t W, int32_t N, int32_t NW) {
+  const int32_t mn = W < N ? W : N, mx = W < N ? N : W;
+  return NW >= mx ? mn : (NW <= mn ? mx : (int32_t)((uint32_t)W + (uint32_t)N - (uint32_t)NW));
+}
+__device__ __forceinline__ uint32_t RowGuess(uint32_t pred, int32_t W, int32_t N, int32_t NW) {
+  const uint32_t g = (uint32_t)ClampedGradient32(W, N, NW);
+  return pred == 0 ? 0u : (pred == 1 ? (uint32_t)W : (pred == 2 ? (uint32_t)N : g));
+}
 template <bool kU8Out>
 __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
                             uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, int lane) {
@@ -607,7 +622,7 @@ __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_ge
     int32_t r_next = (row_active && lane == 0 && kind == kChanResid) ? prow[0] : cvalue;
     const int steps = w + nrows - 1;
     for (int t = 0; t < steps; t++) {
-      const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
+      const int32_t from_up = FromLaneBelow(val);   // lane r-1's value of the previous step = sample (x, y-1)
       const int x = t - lane;
       const int32_t r = r_next;
       if (row_active && kind == kChanResid && x + 1 >= 0 && x + 1 < w) r_next = prow[x + 1];   // in flight during this step
@@ -616,14 +631,7 @@ __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_ge
         if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
         else if (y) { NW = N; N = n_in; }
         else { NW = W; N = W; }
-        uint32_t guess;
-        if (pred == 0) guess = 0;
-        else if (pred == 1) guess = (uint32_t)W;
-        else if (pred == 2) guess = (uint32_t)N;
-        else {
-          const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
-          guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
-        }
+        const uint32_t guess = RowGuess(pred, W, N, NW);
         val = (int32_t)((uint32_t)r + guess);
         if (kU8Out) out8[(size_t)y * out_stride + x] = (uint8_t)(val < 0 ? 0 : (val > 255 ? 255 : val));
         else prow[x] = val;
@@ -638,7 +646,11 @@ __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_ge
 // blocks; a block is loaded into an LDS tile row by row (lanes along x), the skewed pass runs inside the tile, and the
 // results leave it row by row again.  (Reading 64 different rows per step straight from HBM costs a cache line per
 // 4-byte sample once thousands of wavefronts run: measured 404 MB of traffic per 4K alpha plane instead of 41 MB.)
-// W / N / NW live in registers and simply carry over from block to block.  tile: 64 x 65 ints of LDS.
+// W / N / NW live in registers and simply carry over from block to block.  tile: 64 x 64 ints of LDS, pitch 64 ON PURPOSE: the
+// skewed pass has lane r at column t - r, i.e. word r * pitch + t - r; with the usual padded pitch of 65 that is r * 64 + t - every
+// lane in the same bank (the SQ counters showed 83 % of this kernel's LDS cycles as bank conflicts); 63 * r spreads over all banks,
+// and the row-wise load / store phases are conflict-free with any pitch.
+constexpr int kTilePitch = 64;
 template <bool kU8Out>
 __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
                                  uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, JXL_LDS int32_t* tile, int lane) {
@@ -654,41 +666,73 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
     int32_t W = 0, N = 0, NW = 0, val = 0;
     for (int x0 = 0; x0 < w; x0 += 64) {
       const int ncols = min(64, w - x0);
+      // sixteen row loads in flight, then sixteen LDS stores (a load-store-per-row loop waited for every row: 64 serial memory
+      // round trips per block, which was most of this function's time)
       if (kind == kChanResid && lane < ncols)
-        for (int r = 0; r < nrows; r++) tile[r * 65 + lane] = plane[(size_t)(y0 + r) * stride + x0 + lane];
+        for (int r0 = 0; r0 < nrows; r0 += 16) {
+          int32_t v[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) v[i] = plane[(size_t)(y0 + min(r0 + i, nrows - 1)) * stride + x0 + lane];
+#pragma unroll
+          for (int i = 0; i < 16; i++) if (r0 + i < nrows) tile[(r0 + i) * kTilePitch + lane] = v[i];
+        }
       __syncthreads();
       const int steps = ncols + nrows - 1;
+      // The residual of the step after this one and (lane 0) the sample above it are requested a step early: LDS latency
+      // then overlaps the arithmetic instead of adding to the recurrence.
+      JXL_LDS int32_t* const trow = tile + lane * kTilePitch;
+      int32_t r_next = cvalue, up0_next = 0;
+      if (lane == 0 && row_active) {
+        if (kind == kChanResid) r_next = trow[0];
+        if (y) up0_next = carry[x0];
+      }
       for (int t = 0; t < steps; t++) {
-        const int32_t from_up = __shfl_up(val, 1);   // lane r-1's value of the previous step = sample (x, y-1)
+        const int32_t from_up = FromLaneBelow(val);   // lane r-1's value of the previous step = sample (x, y-1)
         const int c = t - lane;
+        const int32_t r = r_next, up0 = up0_next;
+        if (row_active && c + 1 >= 0 && c + 1 < ncols) {
+          if (kind == kChanResid) r_next = trow[c + 1];
+          if (lane == 0 && y) up0_next = carry[x0 + c + 1];
+        }
         if (row_active && c >= 0 && c < ncols) {
           const int x = x0 + c;
-          const int32_t r = kind == kChanResid ? tile[lane * 65 + c] : cvalue;
-          const int32_t n_in = lane == 0 ? (y ? carry[x] : 0) : from_up;
+          const int32_t n_in = lane == 0 ? up0 : from_up;
           if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
           else if (y) { NW = N; N = n_in; }
           else { NW = W; N = W; }
-          uint32_t guess;
-          if (pred == 0) guess = 0;
-          else if (pred == 1) guess = (uint32_t)W;
-          else if (pred == 2) guess = (uint32_t)N;
-          else {
-            const int64_t mn = W < N ? W : N, mx = W < N ? N : W, gr = (int64_t)W + N - NW;
-            guess = (uint32_t)(int32_t)(gr < mn ? mn : (gr > mx ? mx : gr));
-          }
-          val = (int32_t)((uint32_t)r + guess);
-          tile[lane * 65 + c] = val;
+          val = (int32_t)((uint32_t)r + RowGuess(pred, W, N, NW));
+          trow[c] = val;
           if (more && lane == nrows - 1) carry[x] = val;
           W = val;
         }
       }
       __syncthreads();
-      if (lane < ncols)
-        for (int r = 0; r < nrows; r++) {
-          const int32_t v = tile[r * 65 + lane];
-          if (kU8Out) out8[(size_t)(y0 + r) * out_stride + x0 + lane] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
-          else plane[(size_t)(y0 + r) * stride + x0 + lane] = v;
+      if (kU8Out && ncols == 64 && ((out_stride | x0) & 3) == 0 && ((uintptr_t)out8_generic & 3) == 0) {
+        // four samples per lane: one 16-byte LDS read, one packed 4-byte store; a wavefront instruction covers four rows
+        const int l16 = lane & 15, lr = lane >> 4;
+#pragma unroll 4
+        for (int r0 = 0; r0 < nrows; r0 += 4) {
+          const int r = r0 + lr;
+          if (r < nrows) {
+            const I4 v = *(const JXL_LDS I4*)(tile + r * kTilePitch + 4 * l16);
+            const uint32_t px = (uint32_t)min(max(v.x, 0), 255) | (uint32_t)min(max(v.y, 0), 255) << 8 | (uint32_t)min(max(v.z, 0), 255) << 16 |
+                                (uint32_t)min(max(v.w, 0), 255) << 24;
+            *(JXL_GLB uint32_t*)(out8 + (size_t)(y0 + r) * out_stride + x0 + 4 * l16) = px;
+          }
         }
+      } else if (lane < ncols) {
+        for (int r0 = 0; r0 < nrows; r0 += 16) {
+          int32_t v[16];
+#pragma unroll
+          for (int i = 0; i < 16; i++) v[i] = tile[min(r0 + i, nrows - 1) * kTilePitch + lane];
+#pragma unroll
+          for (int i = 0; i < 16; i++)
+            if (r0 + i < nrows) {
+              if (kU8Out) out8[(size_t)(y0 + r0 + i) * out_stride + x0 + lane] = (uint8_t)(v[i] < 0 ? 0 : (v[i] > 255 ? 255 : v[i]));
+              else plane[(size_t)(y0 + r0 + i) * stride + x0 + lane] = v[i];
+            }
+        }
+      }
       __syncthreads();
     }
   }

@@ -1,4 +1,4 @@
 set -e
-timeout -k 10 400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu > gpurun_out/exp_pytest.log 2>&1 || { tail -40 gpurun_out/exp_pytest.log; exit 1; }
+timeout -k 10 500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py tests/test_gpu_modular.py -x -q -m gpu > gpurun_out/exp_pytest.log 2>&1 || { tail -40 gpurun_out/exp_pytest.log; exit 1; }
 tail -2 gpurun_out/exp_pytest.log
 echo "== new"; bash tools/benchloop.sh 384

@@ -9,7 +9,7 @@ value = megapixels decoded per second, whole job (all ranks).  With --gpus N eac
 
 Extra objects on the JSON line:
   roofline      dominant kernel = the one with the most time per batch among lf_ans / hf_decode / alpha_ans / alpha_finish /
-                recon_tile / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
+                recon_tile2 / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
                 (jxl bytes + W*H*4)) / the average HIP-event duration of one launch
   cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
 """
@@ -48,7 +48,7 @@ def cpu_baseline(data, width, height, seconds_budget=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "384")))
     ap.add_argument("--lane-stride", type=int, default=0)
@@ -154,18 +154,19 @@ def main():
         chunk = dec.set_option("query_pixel_chunk", 0) or B
         nchunks = (B + chunk - 1) // chunk
         kernels = {"lf_ans": ("lf_ans_kernel", 1, B), "hf_decode": ("hf_decode_kernel", 1, B), "alpha_ans": ("alpha_ans_kernel", 1, B),
-                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile_kernel", nchunks, min(B, chunk)),
+                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile2_kernel", nchunks, min(B, chunk)),
                    "filters+output": ("filter_gab_epf1_kernel", nchunks, min(B, chunk))}
         # the dominant kernel of this run: most time per batch
         dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))
         kname, launches, imgs_per_launch = kernels[dom]
         dom_ms = stage_ms.get(dom, 0.0) / launches          # average duration of ONE launch of that kernel (HIP events on its stream)
         alg_bytes = imgs_per_launch * (len(data) + W * H * C)
-        # HBM traffic of that kernel from the committed PMC passes (profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+        # HBM traffic of that kernel from the newest committed PMC passes (profiles/r*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
         # --pmc WRITE_SIZE in separate runs, gfx950 correction 2*FETCH + WRITE per the micro-architecture guide), scaled to one launch
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            import glob
+            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
             key = [k for k in pmc["kernels"] if k.startswith(kname)][0]
             traffic = int(pmc["kernels"][key]["hbm_bytes_per_image_corrected"] * imgs_per_launch)
         except Exception:

@@ -119,6 +119,7 @@ struct JxlHipDecoder {
   // options
   int lane_stride_override = 0;
   int hf_ring_override = 0;
+  int hf_stride_override = 0;   // experiment knob: lane stride of the HF kernel only
   bool debug_taps = false;
   // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
   int band_first_row = 0, band_rows = 0;
@@ -185,6 +186,7 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   }
   if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
   if (const char* e = getenv("JXLHIP_HF_RING")) hf_ring_override = atoi(e);
+  if (const char* e = getenv("JXLHIP_HF_STRIDE")) hf_stride_override = atoi(e);
 }
 
 JxlHipDecoder::~JxlHipDecoder() {
@@ -433,11 +435,24 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
     while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
-    // measured (MI355X, 4K frames): once a batch holds thousands of sections, fully packed wavefronts win - the workgroups of
-    // this kernel pin ~50 KB of tables in LDS each, and fewer of them leave more CUs to the concurrent pixel stages
-    if (total_groups >= 8192) lane_stride = 1;
+    // measured (MI355X, 4K frames, batch 384): once a batch holds thousands of sections, 32 sections per wavefront
+    // (half-filled wavefronts, five per image instead of three) is the best trade between instruction efficiency and wavefronts
+    // in flight: hf_decode 72 ms (stride 1) / 61 ms (stride 2) / 87 ms (stride 4)
+    if (total_groups >= 8192) lane_stride = 2;
+    if (hf_stride_override > 0) lane_stride = hf_stride_override;
   }
-  const int per_wg = 256 / lane_stride;
+  // Workgroup width of the HF kernel: four wavefronts, or up to eight when the sections are spread thinly over the lanes and one
+  // image's sections would otherwise need a second workgroup (each workgroup stages the image's ~50 KB of tables in LDS).
+  int hf_waves = 4;
+  {
+    int max_ng = 0;
+    for (int i = 0; i < n; i++)
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) max_ng = std::max<int>(max_ng, (int)frames[i].ng);
+    const int per_wave = 64 / lane_stride;
+    const int need = (max_ng + per_wave - 1) / per_wave;
+    if (need > 4 && lane_stride <= 8) hf_waves = std::min(8, need);
+  }
+  const int per_wg = hf_waves * (64 / lane_stride);
   int n_pass_wg = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
@@ -452,7 +467,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (int i = 0; i < n; i++)
       if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
     while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
-    if (alpha_sections >= 8192) alpha_stride = 1;
+    if (alpha_sections >= 8192) alpha_stride = 2;   // measured: alpha_ans 27.8 ms (stride 1) / 22.5 (2) / 26.4 (4) at batch 384
+    if (const char* e = getenv("JXLHIP_ALPHA_STRIDE")) alpha_stride = atoi(e);   // experiment knob
   }
   const int per_alpha_wg = 64 / alpha_stride;
   int n_alpha_wg = 0;
@@ -729,7 +745,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   int hf_ring = npass_t > 256 ? 16 : 32;
   if (hf_ring_override == 16 || hf_ring_override == 32) hf_ring = hf_ring_override;
   lds_hf += (size_t)hf_slots * HfLaneLdsBytes(hf_ring);
-  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0,
+  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0,
                  d_natural_small, s_hf);
   Mark("hf_decode", s_hf, 1);
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries

@@ -1017,7 +1017,7 @@ __device__ __noinline__ void StoreViaGlobalOrder(const uint16_t* order, uint32_t
 // what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
 // (>= the largest task.count of the launch).
 template <bool kLds, int kRing>
-__global__ __launch_bounds__(256) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots,
+__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots,
                                                         const uint16_t* natural_orders_small) {
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
@@ -1548,21 +1548,21 @@ void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream
 
 size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 4) * 8; }
 
-void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
-                    const uint16_t* natural_orders_small, hipStream_t s) {
+void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words,
+                    size_t lds_bytes, const uint16_t* natural_orders_small, hipStream_t s) {
   if (nwg <= 0) return;
   const size_t lane_bytes = (size_t)nslots * HfLaneLdsBytes(32);   // tables in global memory: always the wide window
   if (lds_bytes) {
     if (ring_words == 16) {
       RaiseLds((const void*)hf_decode_kernel<true, 16>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
     } else {
       RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(256), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
     }
   } else {
     RaiseLds((const void*)hf_decode_kernel<false, 32>, lane_bytes);
-    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(256), lane_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
   }
 }
 

@@ -11,7 +11,7 @@ void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, siz
 void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);
-void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
+void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
                     const uint16_t* natural_orders_small, hipStream_t s);
 void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);

@@ -391,6 +391,23 @@ __global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* img
   const int tx = tile % im.wt, ty = tile / im.wt;
   if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
   const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
+  // The quantised coefficients (addresses depend only on the tile) are requested first: their latency overlaps the two dependent
+  // round trips of the cell-table prologue below.
+  const int wp = im.wp, hp = im.hp;
+  I4v qv[4], qvy[4];
+  {
+    const int32_t* qc = im.coef[c];
+    const int32_t* qy = im.coef[1];
+    const int gx = tx * kTS + (tid & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int gy = ty * kTS + (tid >> 4) + 16 * it;
+      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 4);
+      qv[it] = *(const I4v*)(qc + g);
+      if (c != 1) qvy[it] = *(const I4v*)(qy + g);
+      else qvy[it] = I4v{0, 0, 0, 0};
+    }
+  }
   int bad = 0;
   uint32_t info0 = 0;
   float lfv = 0.f;
@@ -430,7 +447,6 @@ __global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* img
     if (tid == 0 && cidx == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
     return;
   }
-  const int wp = im.wp, hp = im.hp;
   const float* const Bl = basis_all;
   // ---- LLF (wavefront 0): lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples, by lane shuffles
   if (tid < 64) {
@@ -466,8 +482,6 @@ __global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* img
                                               : im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor);
     const float qbc = im.qbias[c], qb1 = im.qbias[1], qb3 = im.qbias[3];
     const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
-    const int32_t* qc = im.coef[c];
-    const int32_t* qy = im.coef[1];
     const int x4 = (tid & 15) * 4, yb = tid >> 4;
     const int gx = tx * kTS + x4;
     const int xx = x4 & 7, ccol = x4 >> 3;
@@ -484,11 +498,8 @@ __global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* img
       const uint32_t lng = meta & 15;
       const bool transposed = meta & 16;
       const int yy = y & 7;
-      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 4);
-      const I4v v = *(const I4v*)(qc + g);
+      const I4v v = qv[it], vy = qvy[it];
       float w[4], wy[4];
-      I4v vy = {0, 0, 0, 0};
-      if (c != 1) vy = *(const I4v*)(qy + g);
       if (!transposed) {
         const uint32_t idx = ((uint32_t)yy << lng) + xx;
         const float4 t = *(const float4*)(wt + (size_t)c * nq + idx);

@@ -9,7 +9,7 @@ value = megapixels decoded per second, whole job (all ranks).  With --gpus N eac
 
 Extra objects on the JSON line:
   roofline      dominant kernel = the one with the most time per batch among lf_ans / hf_decode / alpha_ans / alpha_finish /
-                recon_tile2 / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
+                recon_tile / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
                 (jxl bytes + W*H*4)) / the average HIP-event duration of one launch
   cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
 """
@@ -154,7 +154,7 @@ def main():
         chunk = dec.set_option("query_pixel_chunk", 0) or B
         nchunks = (B + chunk - 1) // chunk
         kernels = {"lf_ans": ("lf_ans_kernel", 1, B), "hf_decode": ("hf_decode_kernel", 1, B), "alpha_ans": ("alpha_ans_kernel", 1, B),
-                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile2_kernel", nchunks, min(B, chunk)),
+                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile_kernel", nchunks, min(B, chunk)),
                    "filters+output": ("filter_gab_epf1_kernel", nchunks, min(B, chunk))}
         # the dominant kernel of this run: most time per batch
         dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))

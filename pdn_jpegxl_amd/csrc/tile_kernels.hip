@@ -89,191 +89,7 @@ __device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, flo
 }  // namespace
 
 // ------------------------------------------------------------------ fused reconstruction of one 64x64 tile
-// One channel at a time (Y, X, B); the chroma-from-luma term re-derives the dequantised Y coefficient from the
-// quantised Y plane instead of keeping three coefficient tiles resident, so that the IDCT bases of every size
-// up to 64 fit in LDS next to the tile (2 workgroups per CU).
-constexpr int kBasisFloats = 5440;   // N = 8,16,32,64 at offsets (N*N-64)/3
-// kBasisLds: keep the IDCT bases in LDS (2 workgroups/CU) or read them through L1 (4 workgroups/CU)
-template <bool kBasisLds>
-__global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
-                                                         const float* llf_scale, int ablate) {
-  extern __shared__ __align__(16) uint8_t smem_raw[];
-  float* cfc = (float*)smem_raw;               // kTS * kLP   coefficients, then pixels, of the current channel
-  float* tmpb = cfc + kTS * kLP;               // kTS * kLP   after the vertical pass
-  float* Bl_lds = tmpb + kTS * kLP;            // kBasisFloats (only when kBasisLds)
-  uint32_t* ci = (uint32_t*)(Bl_lds + (kBasisLds ? kBasisFloats : 0));   // 64
-  uint32_t* rq = ci + 64;                      // 64
-  float* lft = (float*)(rq + 64);              // 64   LF samples of the tile / horizontally transformed
-  float* Bs = lft + 64;                        // 85   small DCT bases, c = 1,2,4,8 at offsets (c*c-1)/3
-  float* B816 = Bs + 96;                       // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
-  float* cscale = B816 + 320;                  // 64   per cell: inv_global_scale / raw quant of its varblock
-  const float** cw = (const float**)(cscale + 64);   // 64   per cell: dequant table base
-  uint32_t* cnq = (uint32_t*)(cw + 64);        // 64   per cell: entries per channel in that table
-  const DevImage& im = imgs[blockIdx.y];
-  // One workgroup per (tile, channel): the kernel is bound by the latency of its barrier-separated phases, not by bandwidth,
-  // so three short workgroups in flight beat one that walks the channels (X and B re-read the Y coefficients for chroma from luma).
-  const int tile = blockIdx.x / 3, cidx_wg = blockIdx.x % 3;
-  if (tile >= im.wt * im.ht) return;
-  if (ablate & 16) return;
-  const int tid = threadIdx.x;
-  const int tx = tile % im.wt, ty = tile / im.wt;
-  if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
-  int bad = 0;
-  if (tid < 64) {
-    const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
-    const bool inside = cx < im.w8 && cy < im.h8;
-    const uint32_t info = inside ? im.cellinfo[(size_t)cy * im.w8 + cx] : 0u;
-    ci[tid] = info;
-    rq[tid] = inside ? im.rawq[(size_t)cy * im.w8 + cx] : 1u;
-    if (inside) {
-      if (!(info >> 31)) bad = 1;
-      else {
-        const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
-        const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
-        // blocks larger than the tile, and the rare special 8x8 transforms, are left to the generic kernels
-        bad = ox < 0 || oy < 0 || ox + (1 << lcx) > 8 || oy + (1 << lcy) > 8 || Special(info & 0xFF);
-      }
-    }
-  }
-  if (__syncthreads_or(bad)) {
-    if (tid == 0 && cidx_wg == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
-    return;
-  }
-  const float* Bl = basis_all;
-  if constexpr (kBasisLds) {
-    for (int i = tid; i < kBasisFloats; i += 256) Bl_lds[i] = basis_all[i];
-    Bl = Bl_lds;
-  }
-  if (tid < 85) Bs[tid] = basis_small[tid];
-  for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
-  if (tid < 64) {
-    const uint32_t info = ci[tid];
-    const uint32_t q = t_quant_table[info & 0xFF];
-    const int ix = (info >> 8) & 31, iy = (info >> 13) & 31;
-    cscale[tid] = im.inv_global_scale / (float)rq[(info >> 31) ? tid - iy * 8 - ix : tid];
-    cw[tid] = im.dq[q];
-    cnq[tid] = im.dq_n[q];
-  }
-  __syncthreads();
-  if (ablate & 32) return;
-  const size_t tile_cfl = (size_t)ty * im.wt + tx;
-  const float cfx = im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor;
-  const float cfb = im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor;
-  const float qb0 = im.qbias[0], qb1 = im.qbias[1], qb2 = im.qbias[2], qb3 = im.qbias[3];
-  const int wp = im.wp, hp = im.hp;
-  {
-    const int cidx = cidx_wg;
-    const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
-    const float qbc = c == 0 ? qb0 : (c == 1 ? qb1 : qb2);
-    const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
-    const float cfl = c == 0 ? cfx : (c == 1 ? 0.f : cfb);
-    const int32_t* qc = im.coef[c];
-    const int32_t* qy = im.coef[1];
-    // ---- dequantisation (+ chroma from luma).  Unconditional (clamped) loads, two iterations in flight (hoisting all sixteen
-    // coefficient fetches ahead of the weight gathers was measured: no gain, and the registers cost two workgroups per CU).
-#pragma unroll 2
-    for (int it = 0; it < 16; it++) {
-      const int e = tid + it * 256;
-      const int y = e >> 6, x = e & 63;
-      const int gx = tx * kTS + x, gy = ty * kTS + y;
-      const bool inside = gx < wp && gy < hp;
-      const int cell = (y >> 3) * 8 + (x >> 3);
-      const uint32_t info = ci[cell];
-      const uint32_t s = info & 0xFF, ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
-      const int kx = (x & 7) + 8 * ix, ky = (y & 7) + 8 * iy;
-      const uint32_t lng_log2 = 3 + max(lcx, lcy);
-      // square DCT tables are symmetric: index them row-major so that consecutive lanes read consecutive weights
-      const bool transposed = !Special(s) && lcy > lcx;
-      const uint32_t idx = inside ? (transposed ? ((uint32_t)kx << lng_log2) + ky : ((uint32_t)ky << lng_log2) + kx) : 0u;
-      const float* wt = cw[cell];
-      const uint32_t nq = cnq[cell];
-      const float scale = cscale[cell];
-      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 1);
-      const int32_t v = (ablate & 1) ? (int32_t)idx : qc[g];
-      const float wv = (ablate & 1) ? scale : wt[(size_t)c * nq + idx];
-      float a;
-      if (v == 0) a = 0.f;
-      else if (v == 1) a = qbc;
-      else if (v == -1) a = -qbc;
-      else a = (float)v - qb3 / (float)v;
-      float o = a * (scale * dm) * wv;
-      if (c != 1) {
-        const int32_t vy = (ablate & 1) ? (int32_t)idx : qy[g];
-        const float wy = (ablate & 1) ? scale : wt[(size_t)nq + idx];
-        float ay;
-        if (vy == 0) ay = 0.f;
-        else if (vy == 1) ay = qb1;
-        else if (vy == -1) ay = -qb1;
-        else ay = (float)vy - qb3 / (float)vy;
-        o += cfl * (ay * scale * wy);
-      }
-      cfc[y * kLP + x] = inside ? o : 0.f;
-    }
-    __syncthreads();
-    // ---- LLF: lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples (separable, all in LDS)
-    if (tid < 64) {
-      const int cx8 = tx * 8 + (tid & 7), cy8 = ty * 8 + (tid >> 3);
-      lft[tid] = (cx8 < im.w8 && cy8 < im.h8) ? im.lf_final[c][(size_t)cy8 * im.w8 + cx8] : 0.f;
-    }
-    __syncthreads();
-    float llf_row = 0.f;
-    if (tid < 64 && !(ablate & 8)) {
-      const uint32_t info = ci[tid];
-      if (info >> 31) {
-        const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
-        const int cx = 1 << lcx;
-        const float* Bx = Bs + (cx * cx - 1) / 3 + ix * cx;
-        const float* lf = lft + (tid >> 3) * 8 + (tid & 7) - ix;
-        for (int x = 0; x < cx; x++) llf_row += lf[x] * Bx[x];
-      }
-    }
-    __syncthreads();
-    if (tid < 64) lft[tid] = llf_row;   // lft[y][kx]: horizontally transformed
-    __syncthreads();
-    if (tid < 64) {
-      const uint32_t info = ci[tid];
-      if (info >> 31) {
-        const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
-        const int cx = 1 << lcx, cy = 1 << lcy;
-        const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
-        const float* By = Bs + (cy * cy - 1) / 3 + iy * cy;
-        float acc = 0.f;
-        for (int y = 0; y < cy; y++) acc += lft[(oy + y) * 8 + ox + ix] * By[y];
-        const float sc = llf_scale[lcy * 32 + iy] * llf_scale[lcx * 32 + ix] / (float)(cx * cy);
-        cfc[(oy * 8 + iy) * kLP + ox * 8 + ix] = acc * sc;
-      }
-    }
-    __syncthreads();
-    // ---- vertical pass -> tmpb.
-    // Matrix cores for everything that is at least 16 points in both directions (97 % of this fixture's area): the tile is cut
-    // into sixteen 16x16 sub-blocks, four per wavefront; a sub-block that lies inside one varblock of R rows is the product
-    // Basis_R^T (16 x R) * coefficients (R x 16), accumulated by v_mfma_f32_16x16x4_f32 (exact f32, the same k-ordered fma
-    // chain as the VALU path).  Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], and owns D[4 * (l >> 4) + r][l & 15].
-    const int wave = tid >> 6, l16 = tid & 15, lq = (tid & 63) >> 4;
-    if (!(ablate & 2)) {
-      for (int s4 = 0; s4 < 4; s4++) {
-        const int sb = wave * 4 + s4;
-        const uint32_t inf = ci[(sb >> 2) * 16 + (sb & 3) * 2];
-        if (MfmaSubBlock(inf)) {   // wave-uniform
-          const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
-          const int cy0 = (sb >> 2) * 2, x0 = (sb & 3) * 16;
-          const float* B = (R == 16 ? B816 + 64 : Bl + (R * R - 64) / 3) + lq * R + iy * 8 + l16;
-          const float* cp = cfc + ((cy0 - iy) * 8 + lq) * kLP + x0 + l16;
-          const F4 acc = MfmaChainN(R, B, 4 * R, cp, 4 * kLP);
-          float* o = tmpb + (cy0 * 8 + 4 * lq) * kLP + x0 + l16;
-          o[0] = acc.x; o[kLP] = acc.y; o[2 * kLP] = acc.z; o[3 * kLP] = acc.w;
-        }
-      }
-    }
-    // the rest on the vector ALUs.  One thread = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
-    if (!(ablate & 2)) {
-      const int x = (tid & 31) * 2, cr = tid >> 5;
-      const uint32_t info = ci[cr * 8 + (x >> 3)];
-      if ((info >> 31) && !MfmaSubBlock(ci[(cr >> 1) * 16 + (x >> 4) * 2])) {
-        const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
-        const int R = 8 << lcy;
-        const float* in = cfc + (cr - iy) * 8 * kLP + x;
-        float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+// one basis row (8 outputs) times two inputs: every basis fetch feeds 16 FMAs
 #define JXL_IDCT_STEP(Bp, v0, v1)                                                                  \
   {                                                                                                \
     const float4 b0 = *(const float4*)(Bp);                                                        \
@@ -283,79 +99,11 @@ __global__ __launch_bounds__(256, 4) void recon_tile_kernel(const DevImage* imgs
     a1[0] += v1 * b0.x; a1[1] += v1 * b0.y; a1[2] += v1 * b0.z; a1[3] += v1 * b0.w;                \
     a1[4] += v1 * b1.x; a1[5] += v1 * b1.y; a1[6] += v1 * b1.z; a1[7] += v1 * b1.w;                \
   }
-        if (R == 8) {            // the common sizes read their basis from LDS: no global load inside the pass
-#pragma unroll 2
-          for (int k = 0; k < 8; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
-        } else if (R == 16) {
-          const float* B = B816 + 64 + iy * 8;
-#pragma unroll 2
-          for (int k = 0; k < 16; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
-        } else {
-          const float* B = Bl + (R * R - 64) / 3 + iy * 8;
-          for (int k = 0; k < R; k++) { const float v0 = in[k * kLP], v1 = in[k * kLP + 1]; JXL_IDCT_STEP(B + k * R, v0, v1) }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) { tmpb[(cr * 8 + j) * kLP + x] = a0[j]; tmpb[(cr * 8 + j) * kLP + x + 1] = a1[j]; }
-      }
-    }
-    __syncthreads();
-    // ---- horizontal pass: tmpb -> cfc (the coefficients of this channel are dead now): rows (16 x C) * Basis_C (C x 16).
-    if (!(ablate & 2)) {
-      for (int s4 = 0; s4 < 4; s4++) {
-        const int sb = wave * 4 + s4;
-        const uint32_t inf = ci[(sb >> 2) * 16 + (sb & 3) * 2];
-        if (MfmaSubBlock(inf)) {
-          const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
-          const int cx0 = (sb & 3) * 2, y0 = (sb >> 2) * 16;
-          const float* B = (C == 16 ? B816 + 64 : Bl + (C * C - 64) / 3) + lq * C + ix * 8 + l16;
-          const float* ap = tmpb + (y0 + l16) * kLP + (cx0 - ix) * 8 + lq;
-          const F4 acc = MfmaChainN(C, ap, 4, B, 4 * C);
-          float* o = cfc + (y0 + 4 * lq) * kLP + cx0 * 8 + l16;
-          o[0] = acc.x; o[kLP] = acc.y; o[2 * kLP] = acc.z; o[3 * kLP] = acc.w;
-        }
-      }
-    }
-    // the rest: two adjacent rows per thread
-    if (!(ablate & 2)) {
-      const int y = (tid & 31) * 2, cc = tid >> 5;
-      const uint32_t info = ci[(y >> 3) * 8 + cc];
-      if ((info >> 31) && !MfmaSubBlock(ci[(y >> 4) * 16 + (cc >> 1) * 2])) {
-        const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
-        const int C = 8 << lcx;
-        const float* in = tmpb + y * kLP + (cc - ix) * 8;
-        float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (C == 8) {
-#pragma unroll 2
-          for (int k = 0; k < 8; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B816 + k * 8, v0, v1) }
-        } else if (C == 16) {
-          const float* B = B816 + 64 + ix * 8;
-#pragma unroll 2
-          for (int k = 0; k < 16; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * 16, v0, v1) }
-        } else {
-          const float* B = Bl + (C * C - 64) / 3 + ix * 8;
-          for (int k = 0; k < C; k++) { const float v0 = in[k], v1 = in[k + kLP]; JXL_IDCT_STEP(B + k * C, v0, v1) }
-        }
-#pragma unroll
-        for (int j = 0; j < 8; j++) { cfc[y * kLP + cc * 8 + j] = a0[j]; cfc[(y + 1) * kLP + cc * 8 + j] = a1[j]; }
-      }
-    }
-    __syncthreads();
-    // ---- coalesced copy-out of this channel
-    float* dst = im.xyb[c];
-#pragma unroll
-    for (int it = 0; it < 16; it++) {
-      const int e = tid + it * 256;
-      const int y = e >> 6, x = e & 63;
-      const int gx = tx * kTS + x, gy = ty * kTS + y;
-      if (gx < wp && gy < hp && !(ablate & 4)) dst[(size_t)gy * wp + gx] = cfc[y * kLP + x];
-    }
-    __syncthreads();
-  }
-}
 
-// ------------------------------------------------------------------ fused reconstruction, one LDS tile, three barriers
-// Same arithmetic as recon_tile_kernel (same fma chains, same order) with the phases reorganised around what the
-// profile showed (two thirds of the wave time parked at barriers / on memory):
+// One workgroup per (64x64 tile, channel): dequantisation (+ chroma from luma), LF -> LLF, both IDCT passes in LDS.  Tiles that hold
+// part of a varblock larger than the tile, or a special 8x8 transform, are appended to a per-image list for the generic kernels.
+// The phases are organised around what the profile of the first version showed (two thirds of the wave time parked at its ten
+// barriers / on memory; that version took 118 ms per batch of 384 frames, this one 55):
 //   * one 64x65 tile: both IDCT passes run IN PLACE.  The vertical pass gives wavefront w the column stripe [16w, 16w+16)
 //     (everything a stripe's outputs depend on lies in the same columns), the horizontal pass gives it the row band
 //     [16w, 16w+16); a wavefront fetches all its operands before it stores, so no workgroup barrier is needed inside a
@@ -374,7 +122,7 @@ __device__ __forceinline__ float DequantBias(int32_t v, float qb, float qb3) {
 }
 typedef int __attribute__((ext_vector_type(4))) I4v;
 
-__global__ __launch_bounds__(256, 6) void recon_tile2_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
+__global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
                                                              const float* llf_scale) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
   float* cfc = (float*)smem_raw;                       // kTS * kLP   coefficients -> columns done -> pixels
@@ -888,24 +636,8 @@ __global__ void out_only_kernel(const DevImage* imgs) {
 
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, hipStream_t s) {
-  static const bool basis_lds = getenv("JXLHIP_RECON_BASIS_LDS") != nullptr;
-  const size_t extra = (128 + 64 + 96 + 320 + 64 + 128 + 64) * 4;
-  if (basis_lds) {
-    const size_t lds = (size_t)(2 * kTS * kLP + kBasisFloats) * 4 + extra;
-    static bool raised = false;
-    if (!raised) {
-      (void)hipFuncSetAttribute((const void*)recon_tile_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      raised = true;
-    }
-    hipLaunchKernelGGL(recon_tile_kernel<true>, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
-  } else if (!getenv("JXLHIP_RECON_OLD")) {
-    const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 4 + 128) * 4;
-    hipLaunchKernelGGL(recon_tile2_kernel, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale);
-  } else {
-    size_t lds = (size_t)(2 * kTS * kLP) * 4 + extra;
-    if (getenv("JXLHIP_RECON_LDS")) lds = (size_t)atoi(getenv("JXLHIP_RECON_LDS"));
-    hipLaunchKernelGGL(recon_tile_kernel<false>, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale, getenv("JXLHIP_ABLATE") ? atoi(getenv("JXLHIP_ABLATE")) : 0);
-  }
+  const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 4 + 128) * 4;   // tile, B816, four per-cell words, per-cell table pointers
+  hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale);
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,

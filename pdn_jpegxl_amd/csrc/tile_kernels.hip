@@ -502,8 +502,11 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
 __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs, int ablate) {
   constexpr int TW = 32, TH = 32, HI = 3, HG = 2;
   constexpr int IW = TW + 2 * HI, IH = TH + 2 * HI, GW = TW + 2 * HG, GH = TH + 2 * HG;
+  // LDS: the input tile, overwritten IN PLACE by the Gaborish tile, plus the two difference tiles: 28 KB -> five workgroups per CU
+  // (a separate Gaborish tile made it 34 KB -> four).
   __shared__ float s_in[3][IH][IW + 1];
-  __shared__ float t[3][GH][GW + 1];
+  __shared__ float s_diff[2][GH][GW + 1];
+  float (*t)[IH][IW + 1] = s_in;   // t[c][gy][gx]: Gaborish at input position (gy + 1, gx + 1), stored at input position (gy, gx)
   const DevImage& im = imgs[blockIdx.y];
   if (!im.fused_gab_epf1) return;
   const int w = im.w, h = im.h, wp = im.wp;
@@ -568,22 +571,31 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < GW * GH; e += 256) {
+  // In place, 256 positions (raster order) per round: position (gy, gx) reads inputs (gy..gy+2, gx..gx+2) and is stored at (gy, gx),
+  // which only positions at or before it in raster order read - so a round's stores can only disturb reads of the SAME round
+  // (barrier between its reads and its stores), never a later round's.
+  constexpr int kGabIters = (GW * GH + 255) / 256;
+#pragma unroll 1
+  for (int it = 0; it < kGabIters; it++) {
+    const int e0 = threadIdx.x + it * 256;
+    const int e = min(e0, GW * GH - 1);
     const int gy = e / GW, gx = e % GW;
     const int cy = gy + 1, cx = gx + 1;   // same position in the input tile (halo 3 vs 2)
+    float gab[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      t[c][gy][gx] = s_in[c][cy][cx] * im.gab_w[c][0] +
-                     (s_in[c][cy - 1][cx] + s_in[c][cy + 1][cx] + s_in[c][cy][cx - 1] + s_in[c][cy][cx + 1]) * im.gab_w[c][1] +
-                     (s_in[c][cy - 1][cx - 1] + s_in[c][cy - 1][cx + 1] + s_in[c][cy + 1][cx - 1] + s_in[c][cy + 1][cx + 1]) * im.gab_w[c][2];
+      gab[c] = s_in[c][cy][cx] * im.gab_w[c][0] +
+               (s_in[c][cy - 1][cx] + s_in[c][cy + 1][cx] + s_in[c][cy][cx - 1] + s_in[c][cy][cx + 1]) * im.gab_w[c][1] +
+               (s_in[c][cy - 1][cx - 1] + s_in[c][cy - 1][cx + 1] + s_in[c][cy + 1][cx - 1] + s_in[c][cy + 1][cx + 1]) * im.gab_w[c][2];
     }
+    __syncthreads();
+    if (e0 < GW * GH) { t[0][gy][gx] = gab[0]; t[1][gy][gx] = gab[1]; t[2][gy][gx] = gab[2]; }
   }
   __syncthreads();
   // Channel-weighted absolute differences between horizontal / vertical neighbours, once per pair: the SAD of a pixel against its
-  // neighbour over the plus-shaped support is then five reads instead of thirty.  The tiles overlay the (now dead) input tile.
-  float (*dh)[GW + 1] = (float (*)[GW + 1])&s_in[0][0][0];          // dh[y][x] = sum_c scale_c |t_c[y][x] - t_c[y][x + 1]|
-  float (*dv)[GW + 1] = (float (*)[GW + 1])(&s_in[0][0][0] + GH * (GW + 1));   // dv[y][x] = ... |t_c[y][x] - t_c[y + 1][x]|
-  static_assert(2 * GH * (GW + 1) <= 3 * IH * (IW + 1), "difference tiles must fit the input tile");
+  // neighbour over the plus-shaped support is then five reads instead of thirty.
+  float (*dh)[GW + 1] = s_diff[0];   // dh[y][x] = sum_c scale_c |t_c[y][x] - t_c[y][x + 1]|
+  float (*dv)[GW + 1] = s_diff[1];   // dv[y][x] = ... |t_c[y][x] - t_c[y + 1][x]|
   const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
   for (int e = threadIdx.x; e < GW * GH; e += 256) {
     const int gy = e / GW, gx = e % GW;

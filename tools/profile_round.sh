@@ -1,7 +1,7 @@
 # rocprofv3 summaries of the bench command for profiles/ (run on the GPU box through gpurun)
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 R=${1:-r01}
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -o k -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_stats.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${R}_stats -o k -- python3 bench.py --steps 6 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_stats.log 2>&1
 echo "stats exit=$?"
 cp $(find gpurun_out/${R}_stats -name "*kernel_stats.csv" | head -1) gpurun_out/${R}_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do

@@ -76,7 +76,7 @@ struct LaneBitsT {
       for (int i = 0; i < kBatch; i++) v[i] = filled + i < nwords ? w[filled + i] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < kBatch; i++) ring[((filled + i) & (kRing - 1)) * rs] = v[i];
+    for (int i = 0; i < kBatch; i++) ring[__umul24((filled + i) & (kRing - 1), rs)] = v[i];
     filled += kBatch;
   }
   __device__ __forceinline__ void TopUp() {
@@ -100,7 +100,7 @@ struct LaneBitsT {
   }
   __device__ __forceinline__ void Refill() {
     if (n <= 32) {
-      buf |= (uint64_t)ring[(rd & (kRing - 1)) * rs] << n;
+      buf |= (uint64_t)ring[__umul24(rd & (kRing - 1), rs)] << n;
       n += 32;
       rd++;
     }
@@ -174,7 +174,7 @@ __device__ __forceinline__ uint32_t AnsSym(LaneBits& b, uint32_t& state, typenam
   const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
   const uint32_t off = g ? (y & 0xFFFF) + pos : pos;
   const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
-  state = freq * (state >> 12) + off;
+  state = __umul24(freq, state >> 12) + off;   // 13 x 20 bits: full-rate v_mad_u32_u24 (v_mul_lo_u32 is quarter rate)
   if (state < 65536u) state = (state << 16) | b.Read(16);
   return sym;
 }
@@ -191,7 +191,7 @@ __device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeT
   const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
   const uint32_t off = g ? (y & 0xFFFF) + pos : pos;
   const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
-  state = freq * (state >> 12) + off;
+  state = __umul24(freq, state >> 12) + off;   // 13 x 20 bits: full-rate v_mad_u32_u24 (v_mul_lo_u32 is quarter rate)
   if (state < 65536u) state = (state << 16) | b.Read(16);
   return HybridTail(b, c, sym);
 }
@@ -1109,7 +1109,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 #pragma unroll
         for (int i = 0; i < kQ; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
 #pragma unroll
-        for (int i = 0; i < kQ; i++) if (dfilled + i < lim) dq[(size_t)((dfilled + i) & (kQ - 1)) * nslots] = v[i];
+        for (int i = 0; i < kQ; i++) if (dfilled + i < lim) dq[__umul24((dfilled + i) & (kQ - 1), nslots)] = v[i];
         dfilled = lim;
       }
     }
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
           if (order_staged) {
             const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
             const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-            plane[(size_t)ky * wp + kx] = UnpackSigned(u);
+            plane[__umul24(ky, wp) + kx] = UnpackSigned(u);   // ky < 256, wp < 2^24
           } else {
             StoreViaGlobalOrder(im.order[ord * 3 + (ci == 0 ? 1 : (ci == 1 ? 0 : 2))], k, lng_log2, transposed, plane, wp, UnpackSigned(u));
           }
@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     }
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
-      const U2 d = dq[(size_t)(bi & (kQ - 1)) * nslots];
+      const U2 d = dq[__umul24(bi & (kQ - 1), nslots)];
       bi++;
       bx = d.x & 31; by = (d.x >> 5) & 31;
       const uint32_t s = (d.x >> 10) & 31;
@@ -1162,11 +1162,11 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     uint32_t ctx;
     if (want_nz) {
-      JXL_LDS uint8_t* const cc = col + (size_t)(c * 32) * nslots;
+      JXL_LDS uint8_t* const cc = col + __umul24(c * 32, nslots);
       uint32_t predicted;
       if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)cc[0];
-      else if (by == 0) predicted = cc[(size_t)(bx - 1) * nslots];
-      else predicted = ((uint32_t)cc[(size_t)bx * nslots] + cc[(size_t)(bx - 1) * nslots] + 1) >> 1;
+      else if (by == 0) predicted = cc[__umul24(bx - 1, nslots)];
+      else predicted = ((uint32_t)cc[__umul24(bx, nslots)] + cc[__umul24(bx - 1, nslots)] + 1) >> 1;
       const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
       uint32_t nzc = predicted >= 64 ? 64 : predicted;
       nzc = nzc < 8 ? nzc : 4 + nzc / 2;
@@ -1183,8 +1183,8 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       nzeros = u;
       if (nzeros + covered > size) { err |= kErrBitstream; break; }
       const uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
-      JXL_LDS uint8_t* const cc = col + (size_t)(c * 32 + bx) * nslots;
-      for (uint32_t ix = 0; ix < (1u << lcx); ix++) cc[(size_t)ix * nslots] = fill;
+      JXL_LDS uint8_t* const cc = col + __umul24(c * 32 + bx, nslots);
+      for (uint32_t ix = 0; ix < (1u << lcx); ix++) cc[__umul24(ix, nslots)] = fill;
       if (nzeros) {
         const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
         histo = ctx_offset + nbc * 37 + 458 * block_ctx;
@@ -1206,7 +1206,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         if (order_staged) {
           const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
           const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-          plane[(size_t)ky * wp + kx] = UnpackSigned(u);
+          plane[__umul24(ky, wp) + kx] = UnpackSigned(u);   // ky < 256, wp < 2^24
         } else {
           // blocks of 128 points and up / custom orders: the order entry comes from global memory.  Out of line on purpose: a load
           // whose result merged into the common path made the compiler wait for ALL outstanding stores before every coefficient store.

@@ -143,13 +143,11 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   if (dev < 0) HIP_OK(hipGetDevice(&dev));
   device = dev;
   HIP_OK(hipSetDevice(device));
-  int prio_lo = 0, prio_hi = 0;
-  HIP_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
-  const char* pe = getenv("JXLHIP_PIX_PRIO");
-  const int pmode = pe ? atoi(pe) : 0;   // experiment: 1 = pixel stream at the highest priority, 2 = entropy streams at the highest
-  HIP_OK(hipStreamCreateWithPriority(&own_stream, hipStreamNonBlocking, pmode == 1 ? prio_hi : (pmode == 2 ? prio_lo : 0)));
-  HIP_OK(hipStreamCreateWithPriority(&stream_lf, hipStreamNonBlocking, pmode == 2 ? prio_hi : (pmode == 1 ? prio_lo : 0)));
-  HIP_OK(hipStreamCreateWithPriority(&stream_hf, hipStreamNonBlocking, pmode == 2 ? prio_hi : (pmode == 1 ? prio_lo : 0)));
+  // (measured on MI355X, batch 384: stream priorities and CU masks that confine the entropy streams to part of the chip change
+  // nothing or lose - the three chains already add up to the chip's capacity)
+  HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&stream_lf, hipStreamNonBlocking));
+  HIP_OK(hipStreamCreateWithFlags(&stream_hf, hipStreamNonBlocking));
   for (auto& S : slots) {
     HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));

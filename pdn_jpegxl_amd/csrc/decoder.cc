@@ -117,6 +117,9 @@ struct JxlHipDecoder {
   std::string sticky_error;             // failure of an older, not yet reported batch
   int sticky_status = 0;
   // options
+  // LoadImage's device / pinned result buffers, kept between calls of a thread (a 33 MB hipHostMalloc per call costs milliseconds)
+  uint8_t* li_dev = nullptr; uint8_t* li_host = nullptr; size_t li_cap = 0;
+  void EnsureLoadImageBuffers(size_t bytes);
   int lane_stride_override = 0;
   int hf_ring_override = 0;
   int hf_stride_override = 0;   // experiment knob: lane stride of the HF kernel only
@@ -202,9 +205,21 @@ JxlHipDecoder::~JxlHipDecoder() {
   (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_llf_scale); (void)hipFree(d_natural_small);
   for (auto p : d_natural) (void)hipFree(p);
   for (auto p : d_dq) (void)hipFree(p);
+  if (li_dev) (void)hipFree(li_dev);
+  if (li_host) (void)hipHostFree(li_host);
   if (own_stream) (void)hipStreamDestroy(own_stream);
   if (stream_lf) (void)hipStreamDestroy(stream_lf);
   if (stream_hf) (void)hipStreamDestroy(stream_hf);
+}
+
+void JxlHipDecoder::EnsureLoadImageBuffers(size_t bytes) {
+  if (bytes <= li_cap) return;
+  if (li_dev) { (void)hipFree(li_dev); li_dev = nullptr; }
+  if (li_host) { (void)hipHostFree(li_host); li_host = nullptr; }
+  li_cap = 0;
+  HIP_OK(hipMalloc(&li_dev, bytes));
+  HIP_OK(hipHostMalloc(&li_host, bytes, hipHostMallocDefault));
+  li_cap = bytes;
 }
 
 void JxlHipDecoder::EnsureWs(size_t bytes) {
@@ -1081,8 +1096,6 @@ static JxlHipDecoder* ThreadDecoder() {
 
 DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, ErrorInfo* err) {
   if (!cb || !data) return DecoderStatus_NullParameter;   // Decoder/JxlDecoder.cpp:802-805
-  uint8_t* d_out = nullptr;
-  uint8_t* h_out = nullptr;
   DecoderStatus result = DecoderStatus_Ok;
   try {
     // ---- pass 1: basic info, colour profile, metadata boxes (Decoder/JxlDecoder.cpp:412-793)
@@ -1121,8 +1134,9 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     JxlHipDecoder* dec = ThreadDecoder();
     const int nch = f.ncolor + (has_alpha ? 1 : 0);
     const size_t bytes = (size_t)f.xsize * f.ysize * nch;   // tightly packed, :291-313
-    HIP_OK(hipMalloc(&d_out, bytes));
-    HIP_OK(hipHostMalloc(&h_out, bytes, hipHostMallocDefault));
+    dec->EnsureLoadImageBuffers(bytes);
+    uint8_t* const d_out = dec->li_dev;
+    uint8_t* const h_out = dec->li_host;   // valid for the duration of the setLayerData call, like the reference's buffer (:291-313)
     DecoderStatus st = DecoderStatus_Ok;
     const uint8_t* hd = data;
     uint8_t* od = d_out;
@@ -1145,8 +1159,6 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
   } catch (...) {
     result = DecoderStatus_DecodeError;
   }
-  if (d_out) hipFree(d_out);
-  if (h_out) hipHostFree(h_out);
   return result;
 }
 

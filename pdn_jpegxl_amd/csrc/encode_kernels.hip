@@ -361,89 +361,151 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
 // ------------------------------------------------------------------ ANS coding, one lane per section
 namespace {
 
-struct LaneWriter {
+// ---- one WAVEFRONT per section.  rANS (12-bit precision, 16-bit renormalisation) is a recurrence over the tokens, back to front,
+// that no amount of lanes can split - but everything around it can: per block of 64 tokens the lanes look up cluster, symbol,
+// frequency, slot-map base and 1 / frequency in parallel, lane 0 alone runs the recurrence over those 64 prepared entries (a float
+// multiply and a fix-up instead of an integer division, operands in LDS instead of HBM), and the lanes store the flushes coalesced.
+// The bits are then laid out front to back by all lanes at once: a wavefront prefix sum of the token lengths gives every lane its
+// bit offset, the lanes OR their bits into an LDS staging window, complete words go out coalesced.
+struct WaveScratch {
+  uint32_t freq[64];
+  float rcp[64];
+  uint32_t rbase[64];
+  uint32_t flush[64];
+  uint32_t stage[128];   // bits [32 * wbase, ...) of the section, not yet written out
+};
+
+__device__ __forceinline__ void WaveSync() {
+  // LDS operations of one wavefront execute in program order; this only keeps the compiler from reordering across the point
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+struct WaveWriter {
   uint32_t* out;
-  uint64_t acc;
-  int n;
-  uint64_t words;
-  __device__ void Init(uint8_t* p) { out = (uint32_t*)p; acc = 0; n = 0; words = 0; }
-  __device__ __forceinline__ void Put(int nbits, uint32_t v) {   // nbits <= 32
+  uint32_t* stage;
+  uint64_t bitpos;    // bits written so far (uniform)
+  uint32_t wbase;     // words already in `out` (uniform)
+  int lane;
+  __device__ void Init(uint8_t* p, WaveScratch* sc, int l) {
+    out = (uint32_t*)p; stage = sc->stage; bitpos = 0; wbase = 0; lane = l;
+    stage[lane] = 0; stage[lane + 64] = 0;
+    WaveSync();
+  }
+  // complete words leave the staging window (coalesced), the partial word moves to its front
+  __device__ void Drain() {
+    const uint32_t nfull = (uint32_t)(bitpos >> 5) - wbase;
+    if (!nfull) return;
+    WaveSync();
+    for (uint32_t i = lane; i < nfull; i += 64) out[wbase + i] = stage[i];
+    const uint32_t carry = stage[nfull];
+    WaveSync();
+    for (uint32_t i = lane; i <= nfull + 2 && i < 128; i += 64) stage[i] = 0;
+    WaveSync();
+    if (lane == 0) stage[0] = carry;
+    WaveSync();
+    wbase += nfull;
+  }
+  // the same (nbits <= 32, v) on every lane
+  __device__ void PutUniform(int nbits, uint32_t v) {
     if (!nbits) return;
-    acc |= (uint64_t)(nbits == 32 ? v : (v & ((1u << nbits) - 1))) << n;
-    n += nbits;
-    if (n >= 32) { out[words++] = (uint32_t)acc; acc >>= 32; n -= 32; }
+    if (lane == 0) {
+      const uint64_t V = (uint64_t)(nbits == 32 ? v : (v & ((1u << nbits) - 1))) << (bitpos & 31);
+      const uint32_t wi = (uint32_t)(bitpos >> 5) - wbase;
+      stage[wi] |= (uint32_t)V;
+      if (V >> 32) stage[wi + 1] |= (uint32_t)(V >> 32);
+    }
+    bitpos += (uint64_t)nbits;
+    Drain();
+  }
+  // lane l appends `len` (<= 48) bits `V` after the bits of lanes < l
+  __device__ void PutParallel(uint64_t V, uint32_t len) {
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if (lane >= d) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (len) {
+      const uint64_t o = bitpos + (incl - len);
+      const uint32_t wi = (uint32_t)(o >> 5) - wbase, sh = (uint32_t)o & 31;
+      const uint32_t w0 = (uint32_t)(V << sh);
+      const uint64_t rest = V >> (32 - sh);   // bits 32.. of V << sh (sh == 0: V >> 32)
+      if (w0) atomicOr(&stage[wi], w0);
+      if ((uint32_t)rest) atomicOr(&stage[wi + 1], (uint32_t)rest);
+      if (rest >> 32) atomicOr(&stage[wi + 2], (uint32_t)(rest >> 32));
+    }
+    bitpos += total;
+    Drain();
   }
   __device__ uint64_t Finish() {   // returns the bit count, pads the last word with zeros
-    const uint64_t bits = words * 32 + n;
-    if (n) out[words++] = (uint32_t)acc;
-    return bits;
+    Drain();
+    if ((bitpos & 31) && lane == 0) out[wbase] = stage[0];
+    return bitpos;
   }
 };
 
-// rANS with 12-bit precision and 16-bit renormalisation.  The decoder consumes the stream front to back, so the state
-// is run over the tokens back to front (recording what each step flushes), then the bits are laid out front to back.
-__device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, LaneWriter& w) {
-  // Both passes walk the token array in blocks of eight with the next block already in flight: the array lives in HBM and a
-  // lane that waits for every token pays a full memory round trip per token (the state recurrence itself is ~40 instructions).
-  // (tokens are read as DevToken, the type they are written as: the forward pass must see the flushes of the reverse pass)
+__device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveWriter& w, WaveScratch* sc) {
+  const int lane = w.lane;
   const DevToken kNone = {0u, 0u};
-  uint32_t state = 0x130000u;
+  const int64_t nblk = ((int64_t)n + 63) >> 6;
+  uint32_t state = 0x130000u;   // lane 0's copy is the real one
   {
-    DevToken cur[8], nxt[8];
-    int64_t base = (int64_t)n - 8;   // block [base, base + 8) clipped to [0, n)
-#pragma unroll
-    for (int k = 0; k < 8; k++) cur[k] = base + k >= 0 ? tok[base + k] : kNone;
-    for (; base > -8; base -= 8) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) nxt[k] = base - 8 + k >= 0 ? tok[base - 8 + k] : kNone;
-#pragma unroll
-      for (int k = 7; k >= 0; k--) {
-        const int64_t r = base + k;
-        if (r < 0) continue;
-        const uint32_t ctx = cur[k].ctx, value = cur[k].value;
-        const uint32_t cl = code.ctx_map[ctx];
-        uint32_t sym, nb, bits;
-        HybridD(value, &sym, &nb, &bits);
-        const uint32_t freq = code.freq[cl * kEncSyms + sym];
-        uint32_t flush = 0;
-        if ((state >> 20) >= freq) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
-        const uint32_t qd = state / freq, rm = state - qd * freq;
-        state = (qd << 12) + code.rmap[(size_t)cl * 4096 + code.start[cl * kEncSyms + sym] + rm];
-        tok[r].ctx = flush;
+    DevToken nxt = kNone;
+    if (nblk) { const int64_t i = (nblk - 1) * 64 + lane; nxt = i < (int64_t)n ? tok[i] : kNone; }
+    for (int64_t b = nblk - 1; b >= 0; b--) {
+      const int64_t idx = b * 64 + lane;
+      const bool valid = idx < (int64_t)n;
+      const DevToken t = nxt;
+      if (b > 0) nxt = tok[idx - 64];   // the block below is in flight while lane 0 works through this one
+      const uint32_t cl = code.ctx_map[t.ctx];
+      uint32_t sym, nb, bits;
+      HybridD(t.value, &sym, &nb, &bits);
+      const uint32_t f = code.freq[cl * kEncSyms + sym];
+      sc->freq[lane] = f;
+      sc->rcp[lane] = 1.0f / (float)max(f, 1u);
+      sc->rbase[lane] = cl * 4096 + code.start[cl * kEncSyms + sym];
+      WaveSync();
+      if (lane == 0) {
+        const int cnt = (int)min<int64_t>(64, (int64_t)n - b * 64);
+        for (int k = cnt - 1; k >= 0; k--) {
+          const uint32_t fk = sc->freq[k];
+          uint32_t flush = 0;
+          if ((state >> 20) >= fk) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
+          // state / fk: the float estimate is within one of the quotient (state < fk << 20, 24-bit mantissas); fixed up exactly
+          uint32_t qd = (uint32_t)((float)state * sc->rcp[k]);
+          int32_t rm = (int32_t)(state - qd * fk);
+          while (rm < 0) { qd--; rm += (int32_t)fk; }
+          while (rm >= (int32_t)fk) { qd++; rm -= (int32_t)fk; }
+          state = (qd << 12) + code.rmap[(size_t)sc->rbase[k] + (uint32_t)rm];
+          sc->flush[k] = flush;
+        }
       }
-#pragma unroll
-      for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+      WaveSync();
+      if (valid) tok[idx].ctx = sc->flush[lane];
     }
   }
-  w.Put(32, state);
+  state = (uint32_t)__shfl((int)state, 0);
+  w.PutUniform(32, state);
   {
-    DevToken cur[8], nxt[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) cur[k] = (uint32_t)k < n ? tok[k] : kNone;
-    for (uint32_t base = 0; base < n; base += 8) {
-#pragma unroll
-      for (int k = 0; k < 8; k++) nxt[k] = base + 8 + k < n ? tok[base + 8 + k] : kNone;
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (base + k >= n) continue;
-        const uint32_t flush = cur[k].ctx, value = cur[k].value;
-        uint32_t sym, nb, bits;
-        HybridD(value, &sym, &nb, &bits);
-        if (flush) w.Put(16, flush & 0xFFFF);
-        w.Put((int)nb, bits);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+    DevToken nxt = kNone;
+    if (nblk) nxt = (uint32_t)lane < n ? tok[lane] : kNone;
+    for (int64_t b = 0; b < nblk; b++) {
+      const int64_t idx = b * 64 + lane;
+      const bool valid = idx < (int64_t)n;
+      const DevToken t = nxt;
+      if (b + 1 < nblk) nxt = idx + 64 < (int64_t)n ? tok[idx + 64] : kNone;
+      uint32_t sym, nb, bits;
+      HybridD(t.value, &sym, &nb, &bits);
+      const uint32_t flush = t.ctx;
+      const uint32_t len = valid ? (flush ? 16u : 0u) + nb : 0u;
+      const uint64_t V = flush ? ((uint64_t)bits << 16) | (flush & 0xFFFF) : (uint64_t)bits;
+      w.PutParallel(V, len);
     }
   }
 }
 
-}  // namespace
-
-namespace {
-
-// Copies the small tables of a code (context map, frequencies, cumulative starts; the slot map too when `with_rmap`) into LDS:
-// a token then costs at most one dependent global load (the slot map of the big HF code) instead of three.
 __device__ size_t StageEncCode(uint8_t* smem, size_t off, const EncCodeDev& g, EncCodeDev* l, bool with_rmap, int tid, int nt) {
   off = (off + 15) & ~(size_t)15;
   const size_t nfs = (size_t)g.num_clusters * kEncSyms;
@@ -462,53 +524,63 @@ __device__ size_t StageEncCode(uint8_t* smem, size_t off, const EncCodeDev& g, E
 
 }  // namespace
 
-// sections [0, nlf): LF groups; [nlf, nlf + ng): pass groups.  kSectionsPerWg lanes of a workgroup own one section each.
-constexpr int kSectionsPerWg = 8;
-__global__ __launch_bounds__(64) void enc_sections_kernel(EncImage im) {
+// sections [0, nlf): LF groups; [nlf, nlf + ng): pass groups.  One wavefront per section, kSectionsPerWg wavefronts per workgroup
+// share the entropy-code tables staged in LDS.
+constexpr int kSectionsPerWg = 4;
+__device__ __forceinline__ WaveScratch* CarveScratch(uint8_t* smem, size_t off, int wave) {
+  off = (off + 15) & ~(size_t)15;
+  return (WaveScratch*)(smem + off) + wave;
+}
+__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_sections_kernel(EncImage im) {
   extern __shared__ __align__(16) uint8_t enc_smem[];
+  size_t off;
   {
     EncCodeDev lm, la;
-    size_t off = StageEncCode(enc_smem, 0, im.mcode, &lm, true, threadIdx.x, 64);
-    StageEncCode(enc_smem, off, im.acode, &la, false, threadIdx.x, 64);
+    off = StageEncCode(enc_smem, 0, im.mcode, &lm, true, threadIdx.x, blockDim.x);
+    off = StageEncCode(enc_smem, off, im.acode, &la, false, threadIdx.x, blockDim.x);
     im.mcode = lm; im.acode = la;
     __syncthreads();
   }
-  if ((int)threadIdx.x >= kSectionsPerWg) return;
-  const int s = blockIdx.x * kSectionsPerWg + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WaveScratch* sc = CarveScratch(enc_smem, off, wave);
+  const int s = blockIdx.x * kSectionsPerWg + wave;
   if (s >= im.nlf + im.ng) return;
-  LaneWriter w;
-  w.Init(im.sec_bytes + (size_t)s * im.sec_cap);
+  WaveWriter w;
+  w.Init(im.sec_bytes + (size_t)s * im.sec_cap, sc, lane);
   if (s < im.nlf) {
     const int g = s;
     const int gx = g % im.xlf, gy = g / im.xlf;
     const int bw = min(kLfGroupBlocks, im.w8 - gx * kLfGroupBlocks), bh = min(kLfGroupBlocks, im.h8 - gy * kLfGroupBlocks);
-    w.Put(2, 0);   // extra_precision
-    w.Put(4, 3);   // modular group header: global tree, default weighted-predictor parameters, no transforms
-    EncodeStream(im.tok_lf + (size_t)g * kLfTokCap, (uint32_t)(3 * bw * bh), im.mcode, w);
-    w.Put(CeilLog2E((uint32_t)(bw * bh)), (uint32_t)(bw * bh - 1));   // number of varblocks - 1
-    w.Put(4, 3);
-    EncodeStream(im.tok_meta + (size_t)g * kMetaTokCap, (uint32_t)(bw * bh), im.mcode, w);
+    w.PutUniform(2, 0);   // extra_precision
+    w.PutUniform(4, 3);   // modular group header: global tree, default weighted-predictor parameters, no transforms
+    EncodeStream(im.tok_lf + (size_t)g * kLfTokCap, (uint32_t)(3 * bw * bh), im.mcode, w, sc);
+    w.PutUniform(CeilLog2E((uint32_t)(bw * bh)), (uint32_t)(bw * bh - 1));   // number of varblocks - 1
+    w.PutUniform(4, 3);
+    EncodeStream(im.tok_meta + (size_t)g * kMetaTokCap, (uint32_t)(bw * bh), im.mcode, w, sc);
   } else {
     const int g = s - im.nlf;
-    EncodeStream(im.tok_ac + (size_t)g * kAcTokCap, im.n_ac[g], im.acode, w);
+    EncodeStream(im.tok_ac + (size_t)g * kAcTokCap, im.n_ac[g], im.acode, w, sc);
     if (im.has_alpha && im.ng > 1) {
       const int gx = g % im.xg, gy = g / im.xg;
       const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
-      w.Put(4, 3);
-      EncodeStream(im.tok_alpha + (size_t)g * kAlphaTokCap, (uint32_t)(gw * gh), im.mcode, w);
+      w.PutUniform(4, 3);
+      EncodeStream(im.tok_alpha + (size_t)g * kAlphaTokCap, (uint32_t)(gw * gh), im.mcode, w, sc);
     }
   }
-  im.sec_bits[s] = w.Finish();
+  const uint64_t bits = w.Finish();
+  if (lane == 0) im.sec_bits[s] = bits;
 }
 
 // single-group frames carry their alpha in the global Modular section: coded on its own (section index nlf + ng)
-__global__ void enc_global_alpha_kernel(EncImage im) {
-  if (threadIdx.x || blockIdx.x) return;
-  LaneWriter w;
+__global__ __launch_bounds__(64) void enc_global_alpha_kernel(EncImage im) {
+  __shared__ WaveScratch sc;
+  if (blockIdx.x) return;
+  WaveWriter w;
   const int s = im.nlf + im.ng;
-  w.Init(im.sec_bytes + (size_t)s * im.sec_cap);
-  EncodeStream(im.tok_alpha, (uint32_t)(im.w * im.h), im.mcode, w);
-  im.sec_bits[s] = w.Finish();
+  w.Init(im.sec_bytes + (size_t)s * im.sec_cap, &sc, threadIdx.x);
+  EncodeStream(im.tok_alpha, (uint32_t)(im.w * im.h), im.mcode, w, &sc);
+  const uint64_t bits = w.Finish();
+  if (threadIdx.x == 0) im.sec_bits[s] = bits;
 }
 
 // gathers the used bytes of every section into one contiguous buffer
@@ -575,16 +647,27 @@ __global__ __launch_bounds__(256) void enc_ll_tokens_kernel(EncImage im) {
     if (s_h[i]) atomicAdd(&im.hist_mod[i], s_h[i]);
 }
 
-__global__ __launch_bounds__(64) void enc_ll_sections_kernel(EncImage im) {
-  const int g = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_ll_sections_kernel(EncImage im) {
+  extern __shared__ __align__(16) uint8_t enc_smem[];
+  size_t off;
+  {
+    EncCodeDev lm;
+    off = StageEncCode(enc_smem, 0, im.mcode, &lm, true, threadIdx.x, blockDim.x);
+    im.mcode = lm;
+    __syncthreads();
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WaveScratch* sc = CarveScratch(enc_smem, off, wave);
+  const int g = blockIdx.x * kSectionsPerWg + wave;
   if (g >= im.ng) return;
   const int gx = g % im.xg, gy = g / im.xg;
   const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
-  LaneWriter w;
-  w.Init(im.sec_bytes + (size_t)g * im.sec_cap);
-  if (im.ng > 1) w.Put(4, 3);   // group header; a single-group frame continues the GlobalModular stream of LfGlobal
-  EncodeStream(im.tok_ll + (size_t)g * kLlTokCap, (uint32_t)(gw * gh * im.ll_nch), im.mcode, w);
-  im.sec_bits[g] = w.Finish();
+  WaveWriter w;
+  w.Init(im.sec_bytes + (size_t)g * im.sec_cap, sc, lane);
+  if (im.ng > 1) w.PutUniform(4, 3);   // group header; a single-group frame continues the GlobalModular stream of LfGlobal
+  EncodeStream(im.tok_ll + (size_t)g * kLlTokCap, (uint32_t)(gw * gh * im.ll_nch), im.mcode, w, sc);
+  const uint64_t bits = w.Finish();
+  if (lane == 0) im.sec_bits[g] = bits;
 }
 
 // ------------------------------------------------------------------ launch wrappers
@@ -607,12 +690,14 @@ void LaunchEncTokens(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_ac_tokens_kernel, dim3(im.ng), dim3(256), 0, s, im);
   if (im.has_alpha) hipLaunchKernelGGL(enc_alpha_tokens_kernel, dim3(32, im.ng), dim3(256), 0, s, im);
 }
+static size_t EncCodeLds(const EncCodeDev& c, bool with_rmap) {   // as StageEncCode carves it
+  return 16 + (size_t)c.num_clusters * (kEncSyms * 4 + (with_rmap ? 8192 : 0)) + c.num_ctx;
+}
 void LaunchEncSections(const EncImage& im, hipStream_t s) {
-  // LDS: modular code with its slot map + HF code without (sizes as StageEncCode carves them)
-  const size_t lds = 64 + (size_t)im.mcode.num_clusters * (kEncSyms * 4 + 8192) + im.mcode.num_ctx + (size_t)im.acode.num_clusters * kEncSyms * 4 +
-                     im.acode.num_ctx;
+  // LDS: modular code with its slot map + HF code without + one scratch block per wavefront
+  const size_t lds = EncCodeLds(im.mcode, true) + EncCodeLds(im.acode, false) + 16 + kSectionsPerWg * sizeof(WaveScratch);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_sections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64), lds, s, im);
+  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im);
   if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
 }
 void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s) {
@@ -620,7 +705,9 @@ void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s) {
     hipLaunchKernelGGL(enc_ll_planes_kernel, dim3(GridFor((size_t)im.w * im.h)), dim3(256), 0, s, im);
     hipLaunchKernelGGL(enc_ll_tokens_kernel, dim3(64, im.ng), dim3(256), 0, s, im);
   } else {
-    hipLaunchKernelGGL(enc_ll_sections_kernel, dim3((unsigned)((im.ng + 63) / 64)), dim3(64), 0, s, im);
+    const size_t lds = EncCodeLds(im.mcode, true) + 16 + kSectionsPerWg * sizeof(WaveScratch);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_ll_sections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(enc_ll_sections_kernel, dim3((unsigned)((im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im);
   }
 }
 void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s) {

@@ -469,6 +469,7 @@ __device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, 
       WaveSync();
       if (lane == 0) {
         const int cnt = (int)min<int64_t>(64, (int64_t)n - b * 64);
+#pragma unroll 4
         for (int k = cnt - 1; k >= 0; k--) {
           const uint32_t fk = sc->freq[k];
           uint32_t flush = 0;

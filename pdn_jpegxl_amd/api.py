@@ -268,6 +268,22 @@ def parse_check(data):
     return DECODER_STATUS[st], list(facts), err.errorMessage.decode("ascii", "replace")
 
 
+def parse_metadata(data, which):
+    """Host-only: the Exif payload (which = 0) or the k-th `xml ` payload (which = k >= 1) as LoadImage would report it
+    (Brotli-compressed `brob` boxes already decompressed); None if absent.  Returns (status, payload, message)."""
+    L = lib()
+    L.jxlhip_parse_metadata.restype = C.c_size_t
+    L.jxlhip_parse_metadata.argtypes = [C.c_char_p, C.c_size_t, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(ErrorInfo)]
+    err = ErrorInfo()
+    st = C.c_int32(0)
+    n = L.jxlhip_parse_metadata(data, len(data), which, None, 0, C.byref(st), C.byref(err))
+    if st.value != 0 or n == 0:
+        return DECODER_STATUS[st.value], None, err.errorMessage.decode("ascii", "replace")
+    buf = (C.c_uint8 * n)()
+    L.jxlhip_parse_metadata(data, len(data), which, buf, n, C.byref(st), C.byref(err))
+    return DECODER_STATUS[st.value], bytes(buf), ""
+
+
 def static_table(name, index, dtype):
     L = lib()
     n = L.jxlhip_static_table(name.encode(), index, None, 0)

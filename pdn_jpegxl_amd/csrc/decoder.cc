@@ -1169,6 +1169,31 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
 // ---------------------------------------------------------------------- host-only introspection (CPU tests)
 extern "C" {
 
+// Metadata boxes as LoadImage would hand them to the host (no GPU): which = 0 Exif, k >= 1 the k-th `xml ` box.  Returns the payload
+// size (0: absent) and copies up to `capacity` bytes.
+JXLFILETYPEIO_API size_t jxlhip_parse_metadata(const uint8_t* data, size_t size, int32_t which, uint8_t* dst, size_t capacity, DecoderStatus* status,
+                                               ErrorInfo* err) {
+  if (status) *status = DecoderStatus_Ok;
+  if (!data) { if (status) *status = DecoderStatus_NullParameter; return 0; }
+  try {
+    ParsedFrame f;
+    ParseFile(data, size, true, f);
+    const uint8_t* p = nullptr;
+    size_t n = 0;
+    if (which == 0) { p = f.exif; n = f.exif_size; }
+    else if (which >= 1 && (size_t)which <= f.xml.size()) { p = f.xml[which - 1].first; n = f.xml[which - 1].second; }
+    if (p && dst && capacity) memcpy(dst, p, std::min(n, capacity));
+    return p ? n : 0;
+  } catch (const ParseError& e) {
+    SetErr(err, "%s", e.what());
+    if (status) *status = (DecoderStatus)e.status;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    if (status) *status = DecoderStatus_DecodeError;
+  }
+  return 0;
+}
+
 // Full host-side parse (no GPU): returns the status and a few facts about the parsed tables.
 // facts[0..7] = tree nodes, modular clusters, modular log_alpha, AC clusters, AC log_alpha, AC contexts, presets, sections
 JXLFILETYPEIO_API DecoderStatus jxlhip_parse_check(const uint8_t* data, size_t size, int32_t* facts, ErrorInfo* err) {

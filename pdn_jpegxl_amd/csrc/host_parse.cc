@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <dlfcn.h>
 #include <mutex>
 
 namespace jxlhip {
@@ -1100,6 +1101,43 @@ void ReadHfGlobal(Bits& r, ParsedFrame& f, std::vector<float> custom_dq[kNumQuan
 
 uint32_t BE32(const uint8_t* p) { return (uint32_t)p[0] << 24 | p[1] << 16 | p[2] << 8 | p[3]; }
 
+// `brob` payloads: Brotli streams.  The decoder library is part of the base image (libbrotlidec.so.1) but its headers are not, and
+// the product must not depend on it at link time: it is bound at first use through its stable C ABI.
+void BrotliDecompress(const uint8_t* in, size_t in_size, std::vector<uint8_t>& out) {
+  typedef void* (*CreateFn)(void*, void*, void*);
+  typedef void (*DestroyFn)(void*);
+  typedef int (*StreamFn)(void*, size_t*, const uint8_t**, size_t*, uint8_t**, size_t*);
+  static std::once_flag once;
+  static CreateFn create = nullptr;
+  static DestroyFn destroy = nullptr;
+  static StreamFn stream = nullptr;
+  std::call_once(once, [] {
+    void* h = dlopen("libbrotlidec.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("libbrotlidec.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    create = (CreateFn)dlsym(h, "BrotliDecoderCreateInstance");
+    destroy = (DestroyFn)dlsym(h, "BrotliDecoderDestroyInstance");
+    stream = (StreamFn)dlsym(h, "BrotliDecoderDecompressStream");
+  });
+  if (!create || !destroy || !stream) Fail("the file holds Brotli-compressed metadata (brob box) and libbrotlidec is not available");
+  void* st = create(nullptr, nullptr, nullptr);
+  if (!st) throw std::bad_alloc();
+  out.clear();
+  std::vector<uint8_t> chunk(1 << 16);
+  size_t avail_in = in_size;
+  const uint8_t* next_in = in;
+  int r;
+  do {
+    size_t avail_out = chunk.size();
+    uint8_t* next_out = chunk.data();
+    r = stream(st, &avail_in, &next_in, &avail_out, &next_out, nullptr);
+    out.insert(out.end(), chunk.data(), next_out);
+    if (out.size() > ((size_t)1 << 30)) { r = 0; break; }   // metadata of a gigabyte: refuse
+  } while (r == 3);   // BROTLI_DECODER_RESULT_NEEDS_MORE_OUTPUT
+  destroy(st);
+  if (r != 1) Fail("corrupt Brotli stream in a brob box");   // BROTLI_DECODER_RESULT_SUCCESS
+}
+
 void SplitContainer(const uint8_t* data, size_t size, ParsedFrame& f) {
   static const uint8_t kSig[12] = {0, 0, 0, 0xC, 'J', 'X', 'L', ' ', 0xD, 0xA, 0x87, 0xA};
   if (size >= 2 && data[0] == 0xFF && data[1] == 0x0A) {
@@ -1132,10 +1170,26 @@ void SplitContainer(const uint8_t* data, size_t size, ParsedFrame& f) {
         f.cs_contiguous = false;
       }
       parts++;
-    } else if (!memcmp(type, "Exif", 4)) {
-      if (!f.exif) { f.exif = pl; f.exif_size = n; }   // first Exif box wins (Decoder/JxlDecoder.cpp:697-719)
-    } else if (!memcmp(type, "xml ", 4)) {
-      f.xml.emplace_back(pl, n);
+    } else {
+      // Brotli-compressed boxes are handed to the host under their inner type with the decompressed payload, exactly as the
+      // reference sees them (JxlDecoderSetDecompressBoxes, Decoder/JxlDecoder.cpp:435; JxlDecoderGetBoxType(..., JXL_TRUE) :691).
+      uint8_t inner[4];
+      if (!memcmp(type, "brob", 4)) {
+        REQUIRE(n >= 4, "brob box too small");
+        memcpy(inner, pl, 4);
+        if (!memcmp(inner, "Exif", 4) || !memcmp(inner, "xml ", 4)) {
+          f.owned_boxes.emplace_back();
+          BrotliDecompress(pl + 4, n - 4, f.owned_boxes.back());
+          pl = f.owned_boxes.back().data();
+          n = f.owned_boxes.back().size();
+        }
+        type = inner;
+      }
+      if (!memcmp(type, "Exif", 4)) {
+        if (!f.exif) { f.exif = pl; f.exif_size = n; }   // first Exif box wins (Decoder/JxlDecoder.cpp:697-719)
+      } else if (!memcmp(type, "xml ", 4)) {
+        f.xml.emplace_back(pl, n);
+      }
     }
     pos += box;
   }

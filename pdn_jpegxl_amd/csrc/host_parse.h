@@ -8,6 +8,7 @@
 #pragma once
 #include <cstdint>
 #include <cstddef>
+#include <deque>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -57,6 +58,7 @@ struct ParsedFrame {
   bool cs_contiguous = true;
   const uint8_t* exif = nullptr; size_t exif_size = 0;
   std::vector<std::pair<const uint8_t*, size_t>> xml;
+  std::deque<std::vector<uint8_t>> owned_boxes;   // decompressed `brob` payloads (exif / xml may point into these)
   // ---- image header
   uint32_t xsize = 0, ysize = 0, orientation = 1;
   uint32_t bits = 8, exp_bits = 0;

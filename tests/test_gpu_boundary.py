@@ -47,3 +47,20 @@ def test_broken_streams_fail_loudly(oracle):
     with pytest.raises(api.FormatError) as e:
         api.load_image(b"not a jxl file at all")
     assert e.value.status == "InvalidFileSignature"
+
+
+@pytest.mark.gpu
+def test_load_image_with_brotli_compressed_metadata(oracle):
+    """`brob` boxes: the callbacks see the decompressed Exif / XMP in the usual order (Decoder/JxlDecoder.cpp:435,687-784)."""
+    import brob_util
+    img = synth(320, 200, 5)
+    exif = b"\0\0\0\0II*\0" + bytes(range(128)) * 4
+    xmp = b"<x:xmpmeta xmlns:x='adobe:ns:meta/'>" + b"0123456789" * 100 + b"</x:xmpmeta>"
+    plain = oracle.encode(img, exif=exif, xmp=xmp)
+    packed = brob_util.compress_metadata_boxes(plain)
+    if packed is None:
+        pytest.skip("no Brotli encoder in this image")
+    a, b = api.load_image(plain), api.load_image(packed)
+    assert b.trace == ["setBasicInfo", "setKnownColorProfile", "setExif", "setXmp", "setLayerData"]
+    assert b.exif == exif and b.xmp == xmp
+    assert np.array_equal(a.pixels, b.pixels)

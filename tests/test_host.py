@@ -100,6 +100,27 @@ def test_metadata_boxes_are_located(oracle):
     assert api.peek(data).width == 300
 
 
+def test_brob_boxes_are_decompressed(oracle):
+    """Brotli-compressed metadata (reference: JxlDecoderSetDecompressBoxes, Decoder/JxlDecoder.cpp:435) reaches the host under its inner type."""
+    import brob_util
+    exif = b"\0\0\0\0II*\0" + bytes(range(200)) * 5
+    xmp = b"<x:xmpmeta xmlns:x='adobe:ns:meta/'>" + b"abcdefgh" * 300 + b"</x:xmpmeta>"
+    plain = oracle.encode(synth(300, 300, 1), exif=exif, xmp=xmp)
+    packed = brob_util.compress_metadata_boxes(plain)
+    if packed is None:
+        pytest.skip("no Brotli encoder in this image")
+    assert len(packed) < len(plain) and b"brob" in packed and b"Exif" in packed
+    assert api.parse_metadata(plain, 0)[:2] == ("Ok", exif) and api.parse_metadata(plain, 1)[:2] == ("Ok", xmp)
+    assert api.parse_metadata(packed, 0)[:2] == ("Ok", exif)
+    assert api.parse_metadata(packed, 1)[:2] == ("Ok", xmp)
+    assert api.parse_metadata(packed, 2)[1] is None
+    # a damaged Brotli stream is a decode error, not a crash and not silently missing metadata
+    k = packed.index(b"brob") + 4 + 4 + 10
+    bad = packed[:k] + bytes([packed[k] ^ 0x5A, packed[k + 1] ^ 0xA5]) + packed[k + 2:]
+    st, payload, msg = api.parse_metadata(bad, 0)
+    assert st == "DecodeError" and "Brotli" in msg or payload != exif
+
+
 def test_static_tables_match_oracle(oracle):
     L = oracle.lib()
     L.jxo_natural_order.restype = C.c_size_t

@@ -651,6 +651,12 @@ __device__ void PredictWave(const I4* tree, int chan, int sid, int32_t* plane_ge
 // lane in the same bank (the SQ counters showed 83 % of this kernel's LDS cycles as bank conflicts); 63 * r spreads over all banks,
 // and the row-wise load / store phases are conflict-free with any pitch.
 constexpr int kTilePitch = 64;
+// The tile belongs to ONE wavefront: its LDS operations execute in program order, so the phases only need the compiler kept in line
+// (a workgroup barrier here would also forbid callers whose wavefronts do different things, like lf_finish_kernel).
+__device__ __forceinline__ void TileSync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 template <bool kU8Out>
 __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
                                  uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, JXL_LDS int32_t* tile, int lane) {
@@ -676,7 +682,7 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
 #pragma unroll
           for (int i = 0; i < 16; i++) if (r0 + i < nrows) tile[(r0 + i) * kTilePitch + lane] = v[i];
         }
-      __syncthreads();
+      TileSync();
       const int steps = ncols + nrows - 1;
       // The residual of the step after this one and (lane 0) the sample above it are requested a step early: LDS latency
       // then overlaps the arithmetic instead of adding to the recurrence.
@@ -706,7 +712,7 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
           W = val;
         }
       }
-      __syncthreads();
+      TileSync();
       if (kU8Out && ncols == 64 && ((out_stride | x0) & 3) == 0 && ((uintptr_t)out8_generic & 3) == 0) {
         // four samples per lane: one 16-byte LDS read, one packed 4-byte store; a wavefront instruction covers four rows
         const int l16 = lane & 15, lr = lane >> 4;
@@ -733,7 +739,7 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
             }
         }
       }
-      __syncthreads();
+      TileSync();
     }
   }
 }
@@ -868,6 +874,8 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
   JXL_LDS int32_t* carry = (JXL_LDS int32_t*)s_carry[wave];
   if (wave < 3) {
     const int chan_of[3] = {1, 0, 2};
+    // (measured: an LDS tile per channel wavefront - 48 KB more per workgroup - doubles this kernel's time in a batch and does not
+    // change the single-frame time; the untiled pass stays)
     FinishChannelI32(desc[wave], tree, wave, 1 + g, im.lfq[chan_of[wave]] + (size_t)by0 * im.w8 + bx0, im.w8, bw, bh, carry, lane);
   } else {
     FinishChannelI32(desc[3], tree, 0, sid_meta, s_x, tw, tw, th, carry, lane);

@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
 // XYB with a 3-pixel halo is staged in LDS, the Gaborish result (2-pixel halo, what the EPF reads) is written to a second LDS
 // tile, the EPF runs from there.  Out-of-frame positions are filled through the mirrored input, which gives the mirrored
 // Gaborish value because the 3x3 kernel is symmetric.  Saves one 24 B/px round trip through HBM and one launch.
-__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs, int ablate) {
+__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs) {
   constexpr int TW = 32, TH = 32, HI = 3, HG = 2;
   constexpr int IW = TW + 2 * HI, IH = TH + 2 * HI, GW = TW + 2 * HG, GH = TH + 2 * HG;
   // LDS: the input tile, overwritten IN PLACE by the Gaborish tile, plus the two difference tiles: 28 KB -> five workgroups per CU
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     sig[it] = im.inv_sigma[(size_t)(yc >> 3) * im.w8 + (xc >> 3)];
     al[it] = im.has_alpha ? im.alpha[(size_t)yc * w + xc] : (uint8_t)255;
   }
-  if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h && !(ablate & 8)) {
+  if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h) {
     // interior tile: no mirroring; rows [y0 - 3, y0 + 35) x columns [x0 - 4, x0 + 36) as aligned 16-byte loads
     constexpr int kQ = (TW + 8) / 4;   // 10 quads per row
     float4 q[2][3];
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
       const int e = e0 < IW * IH ? e0 : IW * IH - 1;
       const int ly = e / IW, lx = e % IW;
       const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
-      const float v0 = (ablate & 1) ? (float)lx : in0[g], v1 = (ablate & 1) ? (float)ly : in1[g], v2 = (ablate & 1) ? 0.5f : in2[g];
+      const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
       s_in[0][ly][lx] = v0;
       s_in[1][ly][lx] = v1;
       s_in[2][ly][lx] = v2;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
     const int cy = ly + HG, cx = lx + HG;
     const float is = sig[it];
     float o0 = t[0][cy][cx], o1 = t[1][cy][cx], o2 = t[2][cy][cx];
-    if (!(is < -3.90524291751269967465540850526868f) && !(ablate & 2)) {
+    if (!(is < -3.90524291751269967465540850526868f)) {
       const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
       const float inv = is * (border ? im.epf_border_sad_mul : 1.0f);
       // SAD against the neighbour above / left / right / below, summed over the support {centre, up, down, left, right}
@@ -628,7 +628,6 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
       o1 = (o1 + w_u * t[1][cy - 1][cx] + w_l * t[1][cy][cx - 1] + w_r * t[1][cy][cx + 1] + w_d * t[1][cy + 1][cx]) * iw;
       o2 = (o2 + w_u * t[2][cy - 1][cx] + w_l * t[2][cy][cx - 1] + w_r * t[2][cy][cx + 1] + w_d * t[2][cy + 1][cx]) * iw;
     }
-    if (ablate & 4) { ((uchar4*)im.out)[(size_t)(y - im.band_y0) * im.w + x] = make_uchar4((uint8_t)(o0 * 255.f), (uint8_t)(o1 * 255.f), (uint8_t)(o2 * 255.f), 255); continue; }
     WritePixelA(im, x, y, o0, o1, o2, al[it]);
   }
 }
@@ -657,8 +656,7 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
-    static const int ablate_f = getenv("JXLHIP_ABLATE_F") ? atoi(getenv("JXLHIP_ABLATE_F")) : 0;
-    hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs, ablate_f);
+    hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);

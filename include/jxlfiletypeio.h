@@ -138,6 +138,8 @@ typedef struct JxlHipImageInfo {
   int32_t num_groups, num_lf_groups;
   int32_t epf_iters, gaborish;
   uint64_t codestream_bytes;
+  int32_t bytes_per_sample;   /* 1: u8 output, 2: u16 output (streams of more than 8 bits per sample) */
+  int32_t reserved;
 } JxlHipImageInfo;
 
 /* device < 0: current HIP device.  Returns NULL on failure (message in err, may be NULL). */
@@ -149,7 +151,7 @@ JXLFILETYPEIO_API DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, Jx
 
 /* Decodes n files.  host_data[i]/sizes[i]: the file bytes in host memory (headers are parsed on the host).
  * dev_data[i]: the same bytes already resident in HBM, or NULL (then they are uploaded inside the call).
- * dev_out[i]: device buffer of width*height*num_channels bytes receiving interleaved u8 pixels.
+ * dev_out[i]: device buffer of width*height*num_channels*bytes_per_sample bytes receiving interleaved u8 (or u16) pixels.
  * Work is enqueued on `stream` (a hipStream_t, may be NULL = default stream); the call returns after
  * enqueueing unless `synchronize` is non-zero.  Per-image status is written to statuses[i] on return when
  * synchronizing, otherwise by jxlhip_finish(). */

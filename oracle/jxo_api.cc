@@ -33,6 +33,7 @@ void jxo_image_info(const JxoImage* im, int32_t* w, int32_t* h, int32_t* nch, in
   *w8 = im->r.frame.xsize_blocks; *h8 = im->r.frame.ysize_blocks;
 }
 const uint8_t* jxo_image_pixels(const JxoImage* im) { return im->r.pixels.data(); }
+int32_t jxo_image_bits_out(const JxoImage* im) { return im->r.bits_out; }   // 8: u8 samples, 16: little-endian u16 samples
 int32_t jxo_image_epf_iters(const JxoImage* im) { return im->r.frame.lf.epf_iters; }
 size_t jxo_image_exif(const JxoImage* im, const uint8_t** p) { *p = im->r.boxes.exif.data(); return im->r.boxes.exif.size(); }
 size_t jxo_image_xml(const JxoImage* im, const uint8_t** p) {
@@ -77,6 +78,7 @@ struct JxoEncodeParams {
   int32_t lossless_squeeze;
   int32_t lossless_tree;
   int32_t num_threads;
+  int32_t bits;   // bits per sample (8..16); above 8 `px` holds uint16 samples
 };
 
 JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
@@ -89,6 +91,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.adaptive_lf_smoothing = ep->adaptive_lf_smoothing != 0;
     p.lossless_predictor = ep->lossless_predictor; p.lossless_squeeze = ep->lossless_squeeze != 0; p.lossless_tree = ep->lossless_tree;
     p.num_threads = ep->num_threads;
+    p.bits = ep->bits ? ep->bits : 8;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

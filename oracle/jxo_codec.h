@@ -30,7 +30,8 @@ struct DecodeResult {
   FrameHeader frame;
   ContainerInfo boxes;
   int num_channels = 0;         // 1,2,3,4 (gray[+a], rgb[+a])
-  std::vector<uint8_t> pixels;  // interleaved u8, tight rows
+  int bits_out = 8;             // 8: `pixels` holds u8 samples; 16: little-endian u16 samples (streams of more than 8 bits per sample)
+  std::vector<uint8_t> pixels;  // interleaved, tight rows
   StageDump dump;
 };
 
@@ -58,6 +59,7 @@ struct EncodeParams {
   bool lossless_squeeze = false;
   int lossless_tree = 0;        // 0: contexts from the weighted predictor's error (property 15); 1: local-gradient contexts (W-NW, NW-N)
   int num_threads = 1;
+  int bits = 8;                 // bits per sample signalled in the header (8..16); above 8 the input samples are uint16
 };
 
 // rgba: interleaved RGBA8 (or RGB8 / Gray8 / GrayA8 according to nch), tight rows.

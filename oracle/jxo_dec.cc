@@ -416,6 +416,20 @@ static uint8_t ToU8(float v) {
   if (v >= 255.0f) return 255;
   return (uint8_t)(v + 0.5f);
 }
+static uint16_t ToU16(float v) {
+  v = v * 65535.0f;
+  if (!(v > 0)) return 0;
+  if (v >= 65535.0f) return 65535;
+  return (uint16_t)(v + 0.5f);
+}
+// Integer sample of `bits` bits -> output type, through [0, 1] floats like the reference's decoder library does for every channel
+// whose depth differs from the output type's; equal depths pass through (clamped).
+static uint32_t IntToOut(int32_t v, uint32_t bits, int bits_out) {
+  const int32_t maxv = (int32_t)((1u << bits) - 1);
+  if ((int)bits == bits_out) return (uint32_t)std::min(maxv, std::max(0, v));
+  const float f = (float)v * (1.0f / (float)maxv);
+  return bits_out == 16 ? ToU16(f) : ToU8(f);
+}
 
 }  // namespace
 
@@ -429,7 +443,7 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   ReadSizeHeader(br, &m.xsize, &m.ysize);
   ReadImageMetadata(br, m);
   JXO_CHECK(!m.color.want_icc, "embedded ICC profiles are not supported yet");
-  JXO_CHECK(m.bits == 8 && m.exp_bits == 0, "only 8-bit integer samples are supported yet");
+  JXO_CHECK(m.bits >= 1 && m.bits <= 16 && m.exp_bits == 0, "only integer samples of up to 16 bits are supported yet");
   br.AlignByte();
   FrameHeader& f = out.frame;
   ReadFrameHeader(br, m, f);
@@ -515,7 +529,14 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   const int alpha_ec = m.alpha_index();
   const int nch = ncolor + (alpha_ec >= 0 ? 1 : 0);
   out.num_channels = nch;
-  out.pixels.assign((size_t)w * h * nch, 0);
+  out.bits_out = m.bits > 8 ? 16 : 8;
+  const int bpo = out.bits_out / 8;
+  out.pixels.assign((size_t)w * h * nch * bpo, 0);
+  auto put = [&](int y, int x, int c, uint32_t v) {
+    const size_t i = ((size_t)y * w + x) * nch + c;
+    if (bpo == 1) out.pixels[i] = (uint8_t)v;
+    else { out.pixels[2 * i] = (uint8_t)(v & 0xFF); out.pixels[2 * i + 1] = (uint8_t)(v >> 8); }
+  };
   if (f.encoding == 0) {
     Plane img[3];
     for (int c = 0; c < 3; c++) {
@@ -554,15 +575,16 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     JXO_CHECK(to_srgb || linear, "only sRGB / linear transfer functions are supported yet");
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
-        uint8_t* o = &out.pixels[((size_t)y * w + x) * nch];
         if (ncolor == 3) {
           for (int c = 0; c < 3; c++) {
             float v = img[c].Row(y)[x];
-            o[c] = ToU8(to_srgb ? LinearToSrgb(v) : v);
+            v = to_srgb ? LinearToSrgb(v) : v;
+            put(y, x, c, bpo == 1 ? ToU8(v) : ToU16(v));
           }
         } else {
           float v = img[1].Row(y)[x];
-          o[0] = ToU8(to_srgb ? LinearToSrgb(v) : v);
+          v = to_srgb ? LinearToSrgb(v) : v;
+          put(y, x, 0, bpo == 1 ? ToU8(v) : ToU16(v));
         }
       }
   } else {
@@ -571,7 +593,7 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
       const Channel& ch = d.full.ch[c];
       JXO_CHECK(ch.w == w && ch.h == h, "modular colour channel size");
       for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) out.pixels[((size_t)y * w + x) * nch + c] = (uint8_t)std::min(255, std::max(0, ch.Row(y)[x]));
+        for (int x = 0; x < w; x++) put(y, x, c, IntToOut(ch.Row(y)[x], m.bits, out.bits_out));
     }
   }
   if (alpha_ec >= 0) {
@@ -579,11 +601,11 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     JXO_CHECK(ci < d.full.ch.size(), "alpha channel missing");
     const Channel& ch = d.full.ch[ci];
     JXO_CHECK(ch.w == w && ch.h == h, "alpha channel size");
-    JXO_CHECK(m.ec[alpha_ec].bits == 8 && m.ec[alpha_ec].exp_bits == 0, "only 8-bit alpha is supported yet");
+    JXO_CHECK(m.ec[alpha_ec].bits >= 1 && m.ec[alpha_ec].bits <= 16 && m.ec[alpha_ec].exp_bits == 0, "only integer alpha of up to 16 bits is supported yet");
     JXO_CHECK(!m.ec[alpha_ec].alpha_associated, "premultiplied alpha is not supported yet");
     if (dump) dump->alpha = ch.d;
     for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) out.pixels[((size_t)y * w + x) * nch + ncolor] = (uint8_t)std::min(255, std::max(0, ch.Row(y)[x]));
+      for (int x = 0; x < w; x++) put(y, x, ncolor, IntToOut(ch.Row(y)[x], m.ec[alpha_ec].bits, out.bits_out));
   }
 }
 

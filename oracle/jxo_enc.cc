@@ -228,14 +228,17 @@ struct VarDctEncoder {
     has_alpha = nch == 2 || nch == 4;
     // 1. sRGB8 -> linear -> XYB
     Plane img[3] = {Plane(w, h), Plane(w, h), Plane(w, h)};
-    float lut[256];
-    for (int i = 0; i < 256; i++) lut[i] = SrgbToLinear(i / 255.0f);
+    const uint32_t maxv = (1u << m.bits) - 1;
+    std::vector<float> lut((size_t)maxv + 1);
+    for (uint32_t i = 0; i <= maxv; i++) lut[i] = SrgbToLinear((float)i / (float)maxv);
     if (has_alpha) alpha.resize((size_t)w * h);
+    const uint16_t* px16 = (const uint16_t*)px;   // samples above 8 bits arrive as uint16
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
-        const uint8_t* s = px + ((size_t)y * w + x) * nch;
-        for (int c = 0; c < 3; c++) img[c].Row(y)[x] = lut[s[ncolor == 3 ? c : 0]];
-        if (has_alpha) alpha[(size_t)y * w + x] = s[ncolor];
+        const size_t o = ((size_t)y * w + x) * nch;
+        auto S = [&](int c) -> uint32_t { return std::min<uint32_t>(maxv, m.bits > 8 ? px16[o + c] : px[o + c]); };
+        for (int c = 0; c < 3; c++) img[c].Row(y)[x] = lut[S(ncolor == 3 ? c : 0)];
+        if (has_alpha) alpha[(size_t)y * w + x] = (int32_t)S(ncolor);
       }
     LinearToXyb(img);
     // 2. approximate inverse of the decoder-side Gaborish: 2*I - K
@@ -484,7 +487,10 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
   for (int c = 0; c < nch; c++) {
     full.ch.emplace_back(w, h, 0, 0);
     for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) full.ch[c].Row(y)[x] = px[((size_t)y * w + x) * nch + c];
+      for (int x = 0; x < w; x++) {
+        const size_t o = ((size_t)y * w + x) * nch + c;
+        full.ch[c].Row(y)[x] = m.bits > 8 ? (int32_t)((const uint16_t*)px)[o] : (int32_t)px[o];
+      }
   }
   GroupHeader gh_global;
   gh_global.use_global_tree = true;
@@ -570,7 +576,9 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   m.color.all_default = false;
   m.color.color_space = nch >= 3 ? 0 : 1;
   m.color.white_point = 1; m.color.primaries = 1; m.color.tf = 13; m.color.rendering_intent = 0;
-  if (nch == 2 || nch == 4) m.ec.push_back(ExtraChannelInfo());
+  JXO_CHECK(p.bits >= 8 && p.bits <= 16, "bits per sample must be 8..16");
+  m.bits = (uint32_t)p.bits;
+  if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = (uint32_t)p.bits; }
   FrameHeader f;
   f.ec_upsampling.assign(m.ec.size(), 1);
   std::vector<uint8_t> frame;

@@ -61,7 +61,8 @@ class IOCallbacks(C.Structure):
 class ImageInfo(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_channels", C.c_int32), ("has_alpha", C.c_int32),
                 ("xsize_blocks", C.c_int32), ("ysize_blocks", C.c_int32), ("num_groups", C.c_int32), ("num_lf_groups", C.c_int32),
-                ("epf_iters", C.c_int32), ("gaborish", C.c_int32), ("codestream_bytes", C.c_uint64)]
+                ("epf_iters", C.c_int32), ("gaborish", C.c_int32), ("codestream_bytes", C.c_uint64), ("bytes_per_sample", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_decoder_create", "jxlhip_decoder_destroy", "jxlhip_peek",
@@ -197,7 +198,10 @@ def load_image(data, fail_at=None):
             return False
         nch = (1 if img.format == "Gray" else 3) + (1 if img.has_transparency else 0)
         n = img.width * img.height * nch
-        img.pixels = np.ctypeslib.as_array(p, shape=(n,)).reshape(img.height, img.width, nch).copy()
+        if img.channel_representation == 1:   # ImageChannelRepresentation.Uint16
+            img.pixels = np.ctypeslib.as_array(p, shape=(2 * n,)).view(np.uint16).reshape(img.height, img.width, nch).copy()
+        else:
+            img.pixels = np.ctypeslib.as_array(p, shape=(n,)).reshape(img.height, img.width, nch).copy()
         img.layer_name = C.string_at(name, nlen - 1).decode("utf-8", "replace") if name and nlen else None
         return True
 

@@ -423,7 +423,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.alpha32 = ws.Take(4 * (size_t)f.xsize * f.ysize);
     chunk_pix = std::max(chunk_pix, pix);
     l.inv_sigma = ws.Take(4 * cells);
-    l.alpha = ws.Take((size_t)f.xsize * f.ysize);
+    l.alpha = ws.Take((size_t)f.xsize * f.ysize * (f.bits > 8 ? 2 : 1));
     l.lf_end = ws.Take(8);
     if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
     total_lf += f.nlf;
@@ -535,6 +535,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.wt = (f.w8 + 7) / 8; d.ht = (f.h8 + 7) / 8;
     d.xg = f.xg; d.yg = f.yg; d.ng = f.ng; d.xlf = f.xlf; d.ylf = f.ylf; d.nlf = f.nlf;
     d.ncolor = f.ncolor; d.has_alpha = f.alpha_index >= 0; d.nch_out = d.ncolor + d.has_alpha;
+    d.sample_bits = (int32_t)f.bits; d.alpha_bits = d.has_alpha ? (int32_t)f.ec[f.alpha_index].bits : 8; d.out_bits = f.bits > 8 ? 16 : 8;
     // band: group rows [b0, b1) are output; one more row each side is decoded for the loop-filter halo
     int b0 = 0, b1 = (int)f.yg;
     if (band_rows > 0 && f.encoding == 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
@@ -971,6 +972,7 @@ DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, JxlHipImageInfo* inf
     info->width = f.xsize; info->height = f.ysize;
     info->has_alpha = f.alpha_index >= 0;
     info->num_channels = f.ncolor + info->has_alpha;
+    info->bytes_per_sample = f.bits > 8 ? 2 : 1;
     info->xsize_blocks = f.w8; info->ysize_blocks = f.h8;
     info->num_groups = f.ng; info->num_lf_groups = f.nlf;
     info->epf_iters = f.epf_iters; info->gaborish = f.gab;
@@ -1107,9 +1109,12 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     if ((f.ncolor != 1 && f.ncolor != 3) || black > 1 || alphas > 1) return DecoderStatus_UnsupportedChannelFormat;   // :485-490
     const bool has_alpha = f.alpha_index >= 0;
     if (black) { SetErr(err, "CMYK images are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
-    if (f.exp_bits > 0 || f.bits > 8) { SetErr(err, "Only 8-bit integer images are supported on the GPU path yet (got %u bits).", f.bits); return DecoderStatus_DecodeError; }
+    // sample type by bit depth (Decoder/JxlDecoder.cpp:510-556): float samples are not decoded on the GPU path yet
+    if (f.exp_bits > 0) { SetErr(err, "Floating point samples are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
+    if (f.bits > 16) { SetErr(err, "Unsupported integer bit depth: %u.", f.bits); return DecoderStatus_DecodeError; }   // :551
+    const bool out16 = f.bits > 8;
     cb->setBasicInfo((int32_t)f.xsize, (int32_t)f.ysize, f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb,
-                     ImageChannelRepresentation_Uint8, has_alpha);   // :558
+                     out16 ? ImageChannelRepresentation_Uint16 : ImageChannelRepresentation_Uint8, has_alpha);   // :558
     // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108)
     {
       const ColorInfo& c = f.color;
@@ -1133,7 +1138,7 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     // ---- pass 2: the frame (Decoder/JxlDecoder.cpp:217-410)
     JxlHipDecoder* dec = ThreadDecoder();
     const int nch = f.ncolor + (has_alpha ? 1 : 0);
-    const size_t bytes = (size_t)f.xsize * f.ysize * nch;   // tightly packed, :291-313
+    const size_t bytes = (size_t)f.xsize * f.ysize * nch * (out16 ? 2 : 1);   // tightly packed, :291-313
     dec->EnsureLoadImageBuffers(bytes);
     uint8_t* const d_out = dec->li_dev;
     uint8_t* const h_out = dec->li_host;   // valid for the duration of the setLayerData call, like the reference's buffer (:291-313)

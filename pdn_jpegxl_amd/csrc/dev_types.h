@@ -65,6 +65,9 @@ struct DevImage {
   int32_t w, h, w8, h8, wp, hp, wt, ht;
   int32_t xg, yg, ng, xlf, ylf, nlf;
   int32_t ncolor, has_alpha, nch_out, to_srgb;
+  // sample depths: the colour channels / the alpha channel as coded (1..16 bits), and the output sample type (8: u8, 16: u16 -
+  // streams of more than 8 bits per sample, reference Decoder/JxlDecoder.cpp:510-556)
+  int32_t sample_bits, alpha_bits, out_bits, pad_bits;
   // codestream
   const uint8_t* cs;
   uint64_t cs_size;
@@ -153,8 +156,8 @@ struct DevImage {
   int32_t final_stage;      // last enabled filter stage (0..3) converts to u8; 4 = no filter, out_only_kernel converts; 5 = fused kernel
   int32_t fused_gab_epf1;   // Gaborish + one EPF iteration run as one kernel (filter_gab_epf1_kernel)
   uint32_t* tile_list;      // 64x64 tiles left to the generic reconstruction kernels (count in status[1])
-  uint8_t* alpha;           // w*h
-  uint8_t* out;             // w*h*nch_out interleaved
+  uint8_t* alpha;           // w*h samples of the OUTPUT type (u8, or u16 when out_bits == 16), already scaled from alpha_bits
+  uint8_t* out;             // w*h*nch_out interleaved samples of the output type
   uint32_t* status;         // [0] error bits, [1..] debug
 };
 
@@ -167,5 +170,6 @@ struct SectionTask {   // one workgroup's share of sections of one image
   int32_t count;   // sections handled by this workgroup
   int32_t pad;
 };
+
 
 }  // namespace jxlhip

@@ -14,6 +14,7 @@
 //  * `lane_stride` picks the mapping: 64 = one section per wavefront, 1 = one section per lane.
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -1294,18 +1295,35 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
   const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
   int32_t* plane = im.alpha32 + (size_t)y0 * im.w + x0;
-  uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
   const int sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
-  if (d.kind == kChanResid) {
-    PredictWaveTiled<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry,
-                           (JXL_LDS int32_t*)s_tile, lane);
-  } else {
-    const bool cst = d.kind == kChanConst;
-    for (int i = lane; i < gw * gh; i += 64) {
-      const size_t o = (size_t)(i / gw) * im.w + (i % gw);
-      const int v = cst ? d.value : plane[o];
-      out[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  if (im.out_bits == 8 && im.alpha_bits == 8) {   // the common case: clamp to u8, packed stores
+    uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
+    if (d.kind == kChanResid) {
+      PredictWaveTiled<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry,
+                             (JXL_LDS int32_t*)s_tile, lane);
+    } else {
+      const bool cst = d.kind == kChanConst;
+      for (int i = lane; i < gw * gh; i += 64) {
+        const size_t o = (size_t)(i / gw) * im.w + (i % gw);
+        const int v = cst ? d.value : plane[o];
+        out[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      }
     }
+    return;
+  }
+  // any other depth: finish the integers in place, then scale them to the output sample type
+  if (d.kind == kChanResid)
+    PredictWaveTiled<false>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, nullptr, 0, (JXL_LDS int32_t*)s_carry,
+                            (JXL_LDS int32_t*)s_tile, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the wavefront reads back what its lanes stored
+  __syncthreads();
+  const bool cst = d.kind == kChanConst;
+  for (int i = lane; i < gw * gh; i += 64) {
+    const size_t o = (size_t)(i / gw) * im.w + (i % gw);
+    const uint32_t v = IntToOutSample(cst ? d.value : plane[o], im.alpha_bits, im.out_bits);
+    const size_t oi = (size_t)y0 * im.w + x0 + o;
+    if (im.out_bits == 16) ((uint16_t*)im.alpha)[oi] = (uint16_t)v;
+    else im.alpha[oi] = (uint8_t)v;
   }
 }
 
@@ -1524,8 +1542,15 @@ __global__ void modular_out_kernel(const DevImage* imgs) {
       if (bc == 0) { v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; }
       else { v[1] = o[0]; v[2] = o[1]; v[3] = o[2]; }
     }
-    uint8_t* out = im.out + i * nch;
-    for (int c = 0; c < nch; c++) out[c] = (uint8_t)(v[c] < 0 ? 0 : (v[c] > 255 ? 255 : v[c]));
+    // colour channels carry sample_bits, the alpha channel (last, if any) alpha_bits; output samples are u8 or u16
+    const int ncol = nch - (im.has_alpha ? 1 : 0);
+    if (im.out_bits == 16) {
+      uint16_t* out = (uint16_t*)im.out + i * nch;
+      for (int c = 0; c < nch; c++) out[c] = (uint16_t)IntToOutSample(v[c], c < ncol ? im.sample_bits : im.alpha_bits, 16);
+    } else {
+      uint8_t* out = im.out + i * nch;
+      for (int c = 0; c < nch; c++) out[c] = (uint8_t)IntToOutSample(v[c], c < ncol ? im.sample_bits : im.alpha_bits, 8);
+    }
   }
 }
 

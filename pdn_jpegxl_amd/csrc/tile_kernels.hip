@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "dev_types.h"
+#include "dev_util.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -59,8 +60,18 @@ __device__ __forceinline__ uint8_t ToU8T(float v) {
   return (uint8_t)(v + 0.5f);
 }
 
+__device__ __forceinline__ uint32_t ToU16T(float v) {
+  v *= 65535.0f;
+  if (!(v > 0.f)) return 0;
+  if (v >= 65535.0f) return 65535;
+  return (uint32_t)(v + 0.5f);
+}
+// The alpha plane holds samples of the output type (alpha_finish_kernel scales them): one u8 or u16 load.
+__device__ __forceinline__ uint32_t LoadAlpha(const DevImage& im, size_t i) {
+  return im.out_bits == 16 ? (uint32_t)((const uint16_t*)im.alpha)[i] : (uint32_t)im.alpha[i];
+}
 // `a`: the pixel's alpha sample (ignored by layouts without alpha), fetched by the caller ahead of the arithmetic
-__device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, float X, float Y, float B, uint8_t a) {
+__device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
   const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
   const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
   float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
@@ -68,9 +79,20 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
   if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
+  if (im.out_bits == 16) {   // streams of more than 8 bits per sample: u16 samples (Decoder/JxlDecoder.cpp:536-548)
+    uint16_t* out = (uint16_t*)im.out + o * im.nch_out;
+    if (im.ncolor == 3) {
+      out[0] = (uint16_t)ToU16T(r); out[1] = (uint16_t)ToU16T(g); out[2] = (uint16_t)ToU16T(bl);
+      if (im.has_alpha) out[3] = (uint16_t)a;
+    } else {
+      out[0] = (uint16_t)ToU16T(g);
+      if (im.has_alpha) out[1] = (uint16_t)a;
+    }
+    return;
+  }
   if (im.nch_out == 4) {
     uchar4 px;
-    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = a;
+    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = (uint8_t)a;
     ((uchar4*)im.out)[o] = px;
   } else {
     uint8_t* out = im.out + o * im.nch_out;
@@ -78,12 +100,12 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
       out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
     } else {
       out[0] = ToU8T(g);
-      if (im.has_alpha) out[1] = a;
+      if (im.has_alpha) out[1] = (uint8_t)a;
     }
   }
 }
 __device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, float X, float Y, float B) {
-  WritePixelA(im, x, y, X, Y, B, im.has_alpha ? im.alpha[(size_t)y * im.w + x] : (uint8_t)255);
+  WritePixelA(im, x, y, X, Y, B, im.has_alpha ? LoadAlpha(im, (size_t)y * im.w + x) : 0u);
 }
 
 }  // namespace
@@ -523,12 +545,12 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
   // a full memory round trip twice more per tile.  Output pixel of iteration `it`: (x0 + lxo, y0 + lyo + 8 * it).
   const int lxo = threadIdx.x & 31, lyo = threadIdx.x >> 5;
   float sig[4];
-  uint8_t al[4];
+  uint32_t al[4];
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int xc = min(x0 + lxo, w - 1), yc = min(y0 + lyo + 8 * it, h - 1);
     sig[it] = im.inv_sigma[(size_t)(yc >> 3) * im.w8 + (xc >> 3)];
-    al[it] = im.has_alpha ? im.alpha[(size_t)yc * w + xc] : (uint8_t)255;
+    al[it] = im.has_alpha ? LoadAlpha(im, (size_t)yc * w + xc) : 0u;
   }
   if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h) {
     // interior tile: no mirroring; rows [y0 - 3, y0 + 35) x columns [x0 - 4, x0 + 36) as aligned 16-byte loads

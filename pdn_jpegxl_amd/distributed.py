@@ -44,7 +44,8 @@ def decode_frame_band(dec, data, rank, world, device="cuda"):
     n_rows = (info.height + 255) // 256
     r0, r1 = band_rows(n_rows, rank, world)
     y0, y1 = min(r0 * 256, info.height), min(r1 * 256, info.height)
-    out = torch.empty(max(1, (y1 - y0) * info.width * info.num_channels), dtype=torch.uint8, device=device)
+    row_bytes = info.width * info.num_channels * info.bytes_per_sample   # u16 samples for streams of more than 8 bits
+    out = torch.empty(max(1, (y1 - y0) * row_bytes), dtype=torch.uint8, device=device)
     if r1 > r0:
         dec.set_option("band_first_row", r0)
         dec.set_option("band_rows", r1 - r0)
@@ -54,7 +55,7 @@ def decode_frame_band(dec, data, rank, world, device="cuda"):
             dec.set_option("band_rows", 0)
         if st[0] != 0:
             raise RuntimeError("band decode failed with status %d" % st[0])
-    return out[: (y1 - y0) * info.width * info.num_channels], (y0, y1)
+    return out[: (y1 - y0) * row_bytes], (y0, y1)
 
 
 def decode_frame_sharded(dec, data, dst=0):
@@ -66,5 +67,9 @@ def decode_frame_sharded(dec, data, dst=0):
     n_rows = (info.height + 255) // 256
     spans = [band_rows(n_rows, r, world) for r in range(world)]
     rows = [min(b * 256, info.height) - min(a * 256, info.height) for a, b in spans]
-    img = gather_bands(band, rows, info.width * info.num_channels, dst=dst)
-    return None if img is None else img.reshape(info.height, info.width, info.num_channels)
+    img = gather_bands(band, rows, info.width * info.num_channels * info.bytes_per_sample, dst=dst)
+    if img is None:
+        return None
+    if info.bytes_per_sample == 2:
+        img = img.view(torch.int16)   # torch has no uint16 arithmetic; callers reinterpret
+    return img.reshape(info.height, info.width, info.num_channels)

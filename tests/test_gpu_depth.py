@@ -1,0 +1,79 @@
+"""GPU parity for streams of more than 8 bits per sample: the host is told Uint16 and receives u16 samples
+(reference: src/JxlFileTypeIO/Decoder/JxlDecoder.cpp:510-556, ImageChannelRepresentation Common.h:33-39)."""
+import numpy as np
+import pytest
+
+from pdn_jpegxl_amd import api
+from pdn_jpegxl_amd.synth import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def synth16(w, h, seed, bits=16):
+    """16-bit version of the synthetic image: the 8-bit pattern in the high byte, a deterministic fine pattern below."""
+    img = synth(w, h, seed).astype(np.uint32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    lo = ((xx * 37 + yy * 101 + seed * 13) & 0xFF).astype(np.uint32)[..., None]
+    v = (img << 8) | lo
+    return (v >> (16 - bits)).astype(np.uint16)
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4])
+def test_lossless_16_bit_is_exact(oracle, nch):
+    img = synth16(300, 270, 7)
+    px = {1: img[..., 1], 2: img[..., [1, 3]], 3: img[..., :3], 4: img}[nch]
+    data = oracle.encode(px, lossless=True, bits=16, lossless_predictor=5, lossless_tree=1)
+    got = api.load_image(data)
+    assert got.channel_representation == 1 and got.pixels.dtype == np.uint16      # Uint16
+    assert got.format == ("Gray" if nch <= 2 else "Rgb") and got.has_transparency == (nch in (2, 4))
+    want = px if px.ndim == 3 else px[..., None]
+    assert np.array_equal(got.pixels, want)                                        # ground truth: lossless
+    assert np.array_equal(got.pixels, oracle.decode(data).pixels)
+
+
+@pytest.mark.parametrize("bits", [10, 12])
+def test_lossless_intermediate_depths_scale_to_16_bit(oracle, bits):
+    px = synth16(260, 200, 3, bits)
+    data = oracle.encode(px, lossless=True, bits=bits)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.channel_representation == 1
+    # value * 65535 / (2^bits - 1) through float32 on both sides: identical up to the rounding of one multiply-add
+    assert np.abs(got.pixels.astype(np.int32) - ref.pixels.astype(np.int32)).max() <= 1
+    exact = np.round(px.astype(np.float64) * 65535 / ((1 << bits) - 1))
+    assert np.abs(got.pixels.astype(np.float64) - exact).max() <= 1
+
+
+@pytest.mark.parametrize("w,h", [(300, 270), (96, 64)])
+def test_lossy_16_bit_matches_oracle(oracle, w, h):
+    px = synth16(w, h, 5)
+    data = oracle.encode(px, distance=1.0, bits=16)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.channel_representation == 1 and got.pixels.shape == (h, w, 4)
+    d = np.abs(got.pixels.astype(np.int32) - ref.pixels.astype(np.int32))
+    # float32 summation order / hardware transcendentals: a few 16-bit steps on the colour channels (0.02 of an 8-bit step), alpha exact
+    assert d[..., :3].max() <= 48 and (d[..., :3] > 8).mean() < 0.002
+    assert np.array_equal(got.pixels[..., 3], px[..., 3])
+    # and the decode is close to the source at 16-bit precision
+    assert np.abs(got.pixels[..., :3].astype(np.float64) - px[..., :3]).mean() < 6 * 257   # distance 1.0 on noisy content
+
+
+def test_8_bit_streams_still_decode_to_u8(oracle):
+    """8-bit streams still come back as u8 (regression guard for the shared output path)."""
+    img = synth(200, 150, 2)
+    got = api.load_image(oracle.encode(img, distance=1.0))
+    assert got.channel_representation == 0 and got.pixels.dtype == np.uint8
+
+
+def test_16_bit_batch_entry_point(oracle):
+    """jxlhip_decode_batch with a u16 output buffer (bytes_per_sample from jxlhip_peek)."""
+    import torch
+    px = synth16(280, 260, 9)[..., :3]
+    data = oracle.encode(px, lossless=True, bits=16, lossless_predictor=5, lossless_tree=1)
+    info = api.peek(data)
+    assert info.bytes_per_sample == 2 and info.num_channels == 3
+    out = torch.zeros(info.width * info.height * info.num_channels * 2, dtype=torch.uint8, device="cuda")
+    dec = api.Decoder(0)
+    st = dec.decode_batch([data], [out.data_ptr()], None, synchronize=True)
+    assert st[0] == 0
+    got = out.cpu().numpy().view(np.uint16).reshape(info.height, info.width, 3)
+    assert np.array_equal(got, px)

@@ -143,3 +143,25 @@ def test_synth_is_deterministic_and_band_consistent():
     b = synth(700, 500, 9, y0=100, y1=300)
     assert (a[100:300] == b).all()
     assert a[..., 3].min() < 255 and not (a[..., 0] == a[..., 1]).all()
+
+
+@pytest.mark.parametrize("bits", [16, 12, 10])
+def test_lossless_round_trip_above_8_bits(oracle, bits):
+    """Ground truth for the deeper sample types: 16-bit lossless is the identity; 10 / 12 bits come back scaled to u16."""
+    rng = np.random.default_rng(bits)
+    px = rng.integers(0, 1 << bits, (70, 90, 4)).astype(np.uint16)
+    d = oracle.decode(oracle.encode(px, lossless=True, bits=bits))
+    assert d.pixels.dtype == np.uint16 and d.pixels.shape == px.shape
+    if bits == 16:
+        assert np.array_equal(d.pixels, px)
+    else:
+        exact = np.round(px.astype(np.float64) * 65535 / ((1 << bits) - 1))
+        assert np.abs(d.pixels.astype(np.float64) - exact).max() <= 1
+
+
+def test_lossy_16_bit_header(oracle):
+    img = synth(128, 96, 4).astype(np.uint16) * 257
+    d = oracle.decode(oracle.encode(img, distance=1.0, bits=16))
+    assert d.pixels.dtype == np.uint16
+    assert np.abs(d.pixels[..., :3].astype(np.float64) - img[..., :3]).mean() < 6 * 257
+    assert np.array_equal(d.pixels[..., 3], img[..., 3])

@@ -29,7 +29,7 @@ JxoImage* jxo_decode(const uint8_t* data, size_t size, int num_threads, int want
 }
 void jxo_image_free(JxoImage* im) { delete im; }
 void jxo_image_info(const JxoImage* im, int32_t* w, int32_t* h, int32_t* nch, int32_t* w8, int32_t* h8) {
-  *w = im->r.frame.xsize; *h = im->r.frame.ysize; *nch = im->r.num_channels;
+  *w = im->r.out_w; *h = im->r.out_h; *nch = im->r.num_channels;   // as displayed (orientation applied)
   *w8 = im->r.frame.xsize_blocks; *h8 = im->r.frame.ysize_blocks;
 }
 const uint8_t* jxo_image_pixels(const JxoImage* im) { return im->r.pixels.data(); }
@@ -79,6 +79,7 @@ struct JxoEncodeParams {
   int32_t lossless_tree;
   int32_t num_threads;
   int32_t bits;   // bits per sample (8..16); above 8 `px` holds uint16 samples
+  int32_t orientation;   // 0 / 1: none; 2..8: EXIF orientation written to the header
 };
 
 JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
@@ -92,6 +93,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.lossless_predictor = ep->lossless_predictor; p.lossless_squeeze = ep->lossless_squeeze != 0; p.lossless_tree = ep->lossless_tree;
     p.num_threads = ep->num_threads;
     p.bits = ep->bits ? ep->bits : 8;
+    p.orientation = ep->orientation ? ep->orientation : 1;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

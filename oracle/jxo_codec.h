@@ -30,6 +30,7 @@ struct DecodeResult {
   FrameHeader frame;
   ContainerInfo boxes;
   int num_channels = 0;         // 1,2,3,4 (gray[+a], rgb[+a])
+  int out_w = 0, out_h = 0;     // size of `pixels`: the frame size with the header's orientation applied (5..8 swap the sides)
   int bits_out = 8;             // 8: `pixels` holds u8 samples; 16: little-endian u16 samples (streams of more than 8 bits per sample)
   std::vector<uint8_t> pixels;  // interleaved, tight rows
   StageDump dump;
@@ -59,6 +60,7 @@ struct EncodeParams {
   bool lossless_squeeze = false;
   int lossless_tree = 0;        // 0: contexts from the weighted predictor's error (property 15); 1: local-gradient contexts (W-NW, NW-N)
   int num_threads = 1;
+  int orientation = 1;          // EXIF orientation written to the header (1..8); the pixels handed in are the STORED image
   int bits = 8;                 // bits per sample signalled in the header (8..16); above 8 the input samples are uint16
 };
 

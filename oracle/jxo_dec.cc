@@ -607,6 +607,31 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) put(y, x, ncolor, IntToOut(ch.Row(y)[x], m.ec[alpha_ec].bits, out.bits_out));
   }
+  // ---- orientation: the decoder library behind the reference hands out the image as it is meant to be displayed
+  // (keep_orientation is off by default), sides swapped for orientations 5..8
+  out.out_w = w; out.out_h = h;
+  if (m.orientation != 1) {
+    const int o = (int)m.orientation;
+    const int ow = o >= 5 ? h : w, oh = o >= 5 ? w : h;
+    const size_t pb = (size_t)nch * bpo;
+    std::vector<uint8_t> t((size_t)ow * oh * pb);
+    for (int oy = 0; oy < oh; oy++)
+      for (int ox = 0; ox < ow; ox++) {
+        int sx, sy;
+        switch (o) {
+          case 2: sx = w - 1 - ox; sy = oy; break;
+          case 3: sx = w - 1 - ox; sy = h - 1 - oy; break;
+          case 4: sx = ox; sy = h - 1 - oy; break;
+          case 5: sx = oy; sy = ox; break;
+          case 6: sx = oy; sy = h - 1 - ox; break;
+          case 7: sx = w - 1 - oy; sy = h - 1 - ox; break;
+          default: sx = w - 1 - oy; sy = ox; break;   // 8
+        }
+        memcpy(&t[((size_t)oy * ow + ox) * pb], &out.pixels[((size_t)sy * w + sx) * pb], pb);
+      }
+    out.pixels.swap(t);
+    out.out_w = ow; out.out_h = oh;
+  }
 }
 
 }  // namespace jxo

@@ -578,6 +578,8 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   m.color.white_point = 1; m.color.primaries = 1; m.color.tf = 13; m.color.rendering_intent = 0;
   JXO_CHECK(p.bits >= 8 && p.bits <= 16, "bits per sample must be 8..16");
   m.bits = (uint32_t)p.bits;
+  JXO_CHECK(p.orientation >= 1 && p.orientation <= 8, "orientation must be 1..8");
+  m.orientation = (uint32_t)p.orientation;
   if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = (uint32_t)p.bits; }
   FrameHeader f;
   f.ec_upsampling.assign(m.ec.size(), 1);

@@ -359,6 +359,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     std::vector<size_t> mod_planes;
     size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
+    size_t orient_tmp = 0;   // frames with an orientation other than 1 are decoded here, then laid out as displayed in the caller's buffer
   };
   std::vector<PerImg> L((size_t)n);
   int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
@@ -436,6 +437,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   std::vector<size_t> chunk_tmp((size_t)pixel_chunk * 3), chunk_xyb((size_t)pixel_chunk * 3);
   if (chunk_pix)
     for (int k = 0; k < pixel_chunk * 3; k++) { chunk_tmp[k] = ws.Take(4 * chunk_pix); chunk_xyb[k] = ws.Take(4 * chunk_pix); }
+  // The reference's decoder library hands out the image as displayed (orientation applied; it is only kept when the caller asks,
+  // which Decoder/DecoderContext.cpp never does): such frames are decoded into a scratch buffer and re-laid out at the end.
+  for (int i = 0; i < n; i++) {
+    if (parse_status[i] != DecoderStatus_Ok || frames[i].orientation == 1) continue;
+    const ParsedFrame& f = frames[i];
+    if (band_rows > 0) { parse_status[i] = DecoderStatus_DecodeError; parse_msg[i] = "band decode of a frame with an orientation is not supported"; continue; }
+    L[i].orient_tmp = ws.Take((size_t)f.xsize * f.ysize * (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (f.bits > 8 ? 2 : 1));
+  }
   // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
   // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
   int lane_stride = 64;
@@ -605,7 +614,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
         }
       d.status = (uint32_t*)(wz + l.z_status);
       status_off[i] = l.z_status;
-      d.out = dev_out[i];
+      d.out = f.orientation == 1 ? dev_out[i] : wr + l.orient_tmp;
       auto code_lds_m = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
       lds_mod = std::max(lds_mod, 64 * 128 + (size_t)mod_lanes * mod_rb * 4 + (mod_wp_lds ? (size_t)mod_lanes * 10 * (mod_rb + 2) * 4 : 0) + 16 +
                                       sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
@@ -681,7 +690,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.hf_start_bits = f.hf_start_bits;
     }
     if (f.tree_uses_wp) { d.wp_lf = (int32_t*)(wr + l.wp_lf); d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * (kGroupDim + 2); }
-    d.out = dev_out[i];
+    d.out = f.orientation == 1 ? dev_out[i] : wr + l.orient_tmp;
     // stage routing (ping-pong between xyb and xyb2)
     float** cur = d.xyb;
     float** other = d.xyb2;
@@ -794,6 +803,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     LaunchModularOut(d_imgs, n, max_mod_pixels, stream);
     Mark("modular", stream, 2);
   }
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].orientation != 1) {
+      const ParsedFrame& f = frames[i];
+      LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (f.bits > 8 ? 2 : 1),
+                   (int)f.orientation, stream);
+    }
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok)
       HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, stream));
@@ -969,7 +984,7 @@ DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, JxlHipImageInfo* inf
   try {
     ParsedFrame f;
     ParseFile(data, size, true, f);
-    info->width = f.xsize; info->height = f.ysize;
+    info->width = f.orientation >= 5 ? f.ysize : f.xsize; info->height = f.orientation >= 5 ? f.xsize : f.ysize;   // as displayed
     info->has_alpha = f.alpha_index >= 0;
     info->num_channels = f.ncolor + info->has_alpha;
     info->bytes_per_sample = f.bits > 8 ? 2 : 1;
@@ -1113,7 +1128,9 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     if (f.exp_bits > 0) { SetErr(err, "Floating point samples are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
     if (f.bits > 16) { SetErr(err, "Unsupported integer bit depth: %u.", f.bits); return DecoderStatus_DecodeError; }   // :551
     const bool out16 = f.bits > 8;
-    cb->setBasicInfo((int32_t)f.xsize, (int32_t)f.ysize, f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb,
+    const bool swap_sides = f.orientation >= 5;   // the host is told the size as displayed
+    cb->setBasicInfo((int32_t)(swap_sides ? f.ysize : f.xsize), (int32_t)(swap_sides ? f.xsize : f.ysize),
+                     f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb,
                      out16 ? ImageChannelRepresentation_Uint16 : ImageChannelRepresentation_Uint8, has_alpha);   // :558
     // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108)
     {

@@ -23,6 +23,8 @@ void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, 
                       int lanes, int rb_width, int wp_lds, hipStream_t s);
 void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
 void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
+// src: w x h pixels of px_bytes each as stored; dst: the same image with EXIF orientation 2..8 applied (sides swapped for 5..8)
+void LaunchOrient(const uint8_t* src, uint8_t* dst, int w, int h, int px_bytes, int orientation, hipStream_t s);
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,

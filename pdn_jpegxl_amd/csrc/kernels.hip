@@ -337,4 +337,31 @@ void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis
   hipLaunchKernelGGL(idct_special_kernel, g, dim3(192), 0, s, imgs, basis_all, basis_small);
 }
 
+// ------------------------------------------------------------------ orientation (rare: one pixel per thread, byte copies)
+__global__ void orient_kernel(const uint8_t* src, uint8_t* dst, int w, int h, int pb, int o) {
+  const int ow = o >= 5 ? h : w, oh = o >= 5 ? w : h;
+  const size_t n = (size_t)ow * oh;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % ow), oy = (int)(i / ow);
+    int sx, sy;
+    switch (o) {
+      case 2: sx = w - 1 - ox; sy = oy; break;
+      case 3: sx = w - 1 - ox; sy = h - 1 - oy; break;
+      case 4: sx = ox; sy = h - 1 - oy; break;
+      case 5: sx = oy; sy = ox; break;
+      case 6: sx = oy; sy = h - 1 - ox; break;
+      case 7: sx = w - 1 - oy; sy = h - 1 - ox; break;
+      default: sx = w - 1 - oy; sy = ox; break;   // 8
+    }
+    const uint8_t* s = src + ((size_t)sy * w + sx) * pb;
+    uint8_t* d = dst + i * pb;
+    for (int k = 0; k < pb; k++) d[k] = s[k];
+  }
+}
+void LaunchOrient(const uint8_t* src, uint8_t* dst, int w, int h, int px_bytes, int orientation, hipStream_t s) {
+  const size_t n = (size_t)w * h;
+  const unsigned blocks = (unsigned)std::min<size_t>(8192, (n + 255) / 256);
+  hipLaunchKernelGGL(orient_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, dst, w, h, px_bytes, orientation);
+}
+
 }  // namespace jxlhip

@@ -77,3 +77,32 @@ def test_16_bit_batch_entry_point(oracle):
     assert st[0] == 0
     got = out.cpu().numpy().view(np.uint16).reshape(info.height, info.width, 3)
     assert np.array_equal(got, px)
+
+
+_ORIENT = {1: lambda a: a, 2: lambda a: a[:, ::-1], 3: lambda a: a[::-1, ::-1], 4: lambda a: a[::-1], 5: lambda a: a.transpose(1, 0, 2),
+           6: lambda a: np.rot90(a, -1), 7: lambda a: a[::-1, ::-1].transpose(1, 0, 2), 8: lambda a: np.rot90(a, 1)}
+
+
+@pytest.mark.parametrize("orientation", [2, 3, 4, 5, 6, 7, 8])
+def test_orientation_is_applied(oracle, orientation):
+    """The decoder library behind the reference returns the image as displayed (keep_orientation is never requested,
+    Decoder/DecoderContext.cpp:98-109): flips / rotations / transpositions per the EXIF numbering, sides swapped for 5..8."""
+    img = synth(330, 270, 11)
+    data = oracle.encode(img, lossless=True, orientation=orientation, lossless_predictor=5, lossless_tree=1)
+    got = api.load_image(data)
+    want = _ORIENT[orientation](img)
+    assert (got.height, got.width) == want.shape[:2]
+    assert np.array_equal(got.pixels, want)                      # ground truth: numpy flips / rot90 of the source
+    assert np.array_equal(got.pixels, oracle.decode(data).pixels)
+    info = api.peek(data)
+    assert (info.height, info.width) == want.shape[:2]
+
+
+def test_orientation_lossy_and_16_bit(oracle):
+    img = synth(300, 260, 12)
+    plain = api.load_image(oracle.encode(img, distance=1.0)).pixels
+    got = api.load_image(oracle.encode(img, distance=1.0, orientation=6)).pixels
+    assert np.array_equal(got, np.rot90(plain, -1))
+    px = synth16(130, 90, 4)
+    got = api.load_image(oracle.encode(px, lossless=True, bits=16, orientation=8)).pixels
+    assert np.array_equal(got, np.rot90(px, 1))

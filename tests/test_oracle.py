@@ -165,3 +165,14 @@ def test_lossy_16_bit_header(oracle):
     assert d.pixels.dtype == np.uint16
     assert np.abs(d.pixels[..., :3].astype(np.float64) - img[..., :3]).mean() < 6 * 257
     assert np.array_equal(d.pixels[..., 3], img[..., 3])
+
+
+def test_orientation_against_numpy(oracle):
+    """Ground truth for the eight EXIF orientations: numpy flips / rot90 / transposes of the un-oriented decode."""
+    img = synth(70, 50, 3)
+    base = oracle.decode(oracle.encode(img, lossless=True)).pixels
+    ops = {1: lambda a: a, 2: lambda a: a[:, ::-1], 3: lambda a: a[::-1, ::-1], 4: lambda a: a[::-1], 5: lambda a: a.transpose(1, 0, 2),
+           6: lambda a: np.rot90(a, -1), 7: lambda a: a[::-1, ::-1].transpose(1, 0, 2), 8: lambda a: np.rot90(a, 1)}
+    for o, f in ops.items():
+        d = oracle.decode(oracle.encode(img, lossless=True, orientation=o)).pixels
+        assert np.array_equal(d, f(base)), o

@@ -1308,6 +1308,9 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   if (f.exp_bits != 0 || f.bits < 1 || f.bits > 16) Fail("only integer samples of up to 16 bits are supported yet");
   if (f.alpha_index >= 0 && (f.ec[f.alpha_index].exp_bits != 0 || f.ec[f.alpha_index].bits < 1 || f.ec[f.alpha_index].bits > 16))
     Fail("only integer alpha of up to 16 bits is supported yet");
+  // the reference asks for un-premultiplied output (Decoder/JxlDecoder.cpp:233): premultiplied streams would need the division
+  if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated) Fail("premultiplied alpha is not supported yet");
+  for (auto& e : f.ec) if (e.dim_shift) Fail("subsampled extra channels are not supported yet");
   if (f.encoding == 0 && !f.xyb_encoded) Fail("VarDCT frames without XYB are not supported yet");
   if (f.encoding == 1 && f.xyb_encoded) Fail("lossy Modular (XYB) frames are not decoded on the GPU path yet");
   if (f.encoding == 1 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u)) Fail("extra channels other than alpha are not supported yet");

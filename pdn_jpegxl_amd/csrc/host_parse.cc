@@ -623,6 +623,10 @@ void ReadFrameHeader(Bits& r, ParsedFrame& f) {
   REQUIRE(f.frame_type == 0 || f.frame_type == 3, "first frame is not a regular frame (LF / reference frames are not supported yet)");
   REQUIRE(!have_crop && upsampling == 1, "cropped or upsampled frames are not supported yet");
   REQUIRE(!do_ycbcr, "YCbCr frames are not supported yet");
+  // The reference keeps the first frame its decoder library hands out (Decoder/JxlDecoder.cpp:398-400), and that library composes
+  // layers: the first DISPLAYED frame is this frame alone only if it ends the file or is an animation frame with a duration.
+  REQUIRE(f.is_last || (f.have_animation && duration > 0), "images composed of several layers are not supported yet");
+  REQUIRE(blend == 0, "frame blend modes other than replace are not supported yet");
   f.group_dim = 128u << f.group_size_shift;
   f.w8 = (f.xsize + 7) / 8; f.h8 = (f.ysize + 7) / 8;
   f.xg = (f.xsize + f.group_dim - 1) / f.group_dim; f.yg = (f.ysize + f.group_dim - 1) / f.group_dim;

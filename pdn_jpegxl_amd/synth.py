@@ -68,3 +68,13 @@ def synth(W, H, seed, noise_sigma=6.0, y0=0, y1=None):
             ys, ye = max(y0, ty * TILE), min(y1, ty * TILE + t.shape[0])
             out[ys - y0:ye - y0, tx * TILE:tx * TILE + t.shape[1]] = t[ys - ty * TILE:ye - ty * TILE]
     return out
+
+
+def synth16(w, h, seed, bits=16):
+    """Deeper-sample version of synth(): the 8-bit pattern in the high byte, a deterministic fine pattern below it; samples use
+    the low `bits` bits of a uint16 (bits in 9..16)."""
+    img = synth(w, h, seed).astype(np.uint32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    lo = ((xx * 37 + yy * 101 + seed * 13) & 0xFF).astype(np.uint32)[..., None]
+    v = (img << 8) | lo
+    return (v >> (16 - bits)).astype(np.uint16)

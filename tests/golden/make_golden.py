@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import numpy as np  # noqa: E402
 import oracle_lib as O  # noqa: E402
-from pdn_jpegxl_amd.synth import synth  # noqa: E402
+from pdn_jpegxl_amd.synth import synth, synth16  # noqa: E402
 
 CASES = {
     "rgba_64x48_d1": dict(size=(64, 48), seed=11, nch=4, enc=dict(distance=1.0)),
@@ -23,12 +23,16 @@ CASES = {
     "gray_270x300_d3": dict(size=(270, 300), seed=14, nch=1, enc=dict(distance=3.0)),
     "rgba_40x30_lossless": dict(size=(40, 30), seed=15, nch=4, enc=dict(lossless=True)),
     "rgb_300x260_lossless_squeeze": dict(size=(300, 260), seed=16, nch=3, enc=dict(lossless=True, lossless_squeeze=True)),
+    "rgba16_96x64_lossless": dict(size=(96, 64), seed=17, nch=4, enc=dict(lossless=True, bits=16)),
+    "rgba12_96x64_d1": dict(size=(96, 64), seed=18, nch=4, enc=dict(distance=1.0, bits=12)),
+    "rgb_80x60_orient6_d1": dict(size=(80, 60), seed=19, nch=3, enc=dict(distance=1.0, orientation=6)),
 }
 
 
 def source(case):
     w, h = case["size"]
-    img = synth(w, h, case["seed"])
+    bits = case["enc"].get("bits", 8)
+    img = synth(w, h, case["seed"]) if bits <= 8 else synth16(w, h, case["seed"], bits)
     nch = case["nch"]
     return {4: img, 3: img[..., :3], 1: img[..., 1:2], 2: img[..., [1, 3]]}[nch]
 

@@ -4,18 +4,9 @@ import numpy as np
 import pytest
 
 from pdn_jpegxl_amd import api
-from pdn_jpegxl_amd.synth import synth
+from pdn_jpegxl_amd.synth import synth, synth16
 
 pytestmark = pytest.mark.gpu
-
-
-def synth16(w, h, seed, bits=16):
-    """16-bit version of the synthetic image: the 8-bit pattern in the high byte, a deterministic fine pattern below."""
-    img = synth(w, h, seed).astype(np.uint32)
-    yy, xx = np.mgrid[0:h, 0:w]
-    lo = ((xx * 37 + yy * 101 + seed * 13) & 0xFF).astype(np.uint32)[..., None]
-    v = (img << 8) | lo
-    return (v >> (16 - bits)).astype(np.uint16)
 
 
 @pytest.mark.parametrize("nch", [1, 2, 3, 4])
@@ -106,3 +97,14 @@ def test_orientation_lossy_and_16_bit(oracle):
     px = synth16(130, 90, 4)
     got = api.load_image(oracle.encode(px, lossless=True, bits=16, orientation=8)).pixels
     assert np.array_equal(got, np.rot90(px, 1))
+
+
+def test_golden_fixtures_of_the_deeper_formats(oracle):
+    """The committed 16-bit / 12-bit / oriented fixtures through LoadImage against the oracle's decode."""
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, tol in (("rgba16_96x64_lossless", 0), ("rgba12_96x64_d1", 48), ("rgb_80x60_orient6_d1", 1)):
+        data = open(os.path.join(gold, name + ".jxl"), "rb").read()
+        got, ref = api.load_image(data).pixels, oracle.decode(data).pixels
+        assert got.shape == ref.shape and got.dtype == ref.dtype, name
+        assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= tol, name

@@ -108,3 +108,26 @@ def test_golden_fixtures_of_the_deeper_formats(oracle):
         got, ref = api.load_image(data).pixels, oracle.decode(data).pixels
         assert got.shape == ref.shape and got.dtype == ref.dtype, name
         assert np.abs(got.astype(np.int32) - ref.astype(np.int32)).max() <= tol, name
+
+
+def test_mixed_batch_of_formats(oracle):
+    """One jxlhip_decode_batch call with 8-bit lossy, 16-bit lossless, 12-bit lossy, an oriented frame and an 8-bit lossless frame:
+    every image carries its own sample depths / orientation through the shared kernels."""
+    import torch
+    a = synth(300, 260, 21)
+    b = synth16(200, 180, 22)
+    files = [oracle.encode(a, distance=1.0), oracle.encode(b, lossless=True, bits=16, lossless_predictor=5, lossless_tree=1),
+             oracle.encode(synth16(260, 140, 23, 12), distance=1.5, bits=12), oracle.encode(a[..., :3], distance=2.0, orientation=5),
+             oracle.encode(a, lossless=True)]
+    infos = [api.peek(f) for f in files]
+    outs = [torch.zeros(i.width * i.height * i.num_channels * i.bytes_per_sample, dtype=torch.uint8, device="cuda") for i in infos]
+    dec = api.Decoder(0)
+    st = dec.decode_batch(files, [o.data_ptr() for o in outs], None, synchronize=True)
+    assert all(s == 0 for s in st), st
+    for f, i, o in zip(files, infos, outs):
+        ref = oracle.decode(f).pixels
+        got = o.cpu().numpy().view(np.uint16 if i.bytes_per_sample == 2 else np.uint8).reshape(i.height, i.width, i.num_channels)
+        assert got.shape == ref.shape
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        assert d.max() <= (48 if i.bytes_per_sample == 2 else 1), (d.max(), i.bytes_per_sample)
+    dec.close()

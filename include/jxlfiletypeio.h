@@ -138,8 +138,8 @@ typedef struct JxlHipImageInfo {
   int32_t num_groups, num_lf_groups;
   int32_t epf_iters, gaborish;
   uint64_t codestream_bytes;
-  int32_t bytes_per_sample;   /* 1: u8 output, 2: u16 output (streams of more than 8 bits per sample) */
-  int32_t reserved;
+  int32_t bytes_per_sample;   /* 1: u8 output; 2: u16 (more than 8 bits per sample) or binary16; 4: binary32 */
+  int32_t reserved;           /* 1: the samples are floats (binary16 / binary32) */
 } JxlHipImageInfo;
 
 /* device < 0: current HIP device.  Returns NULL on failure (message in err, may be NULL). */

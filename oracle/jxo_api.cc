@@ -34,6 +34,7 @@ void jxo_image_info(const JxoImage* im, int32_t* w, int32_t* h, int32_t* nch, in
 }
 const uint8_t* jxo_image_pixels(const JxoImage* im) { return im->r.pixels.data(); }
 int32_t jxo_image_bits_out(const JxoImage* im) { return im->r.bits_out; }   // 8: u8 samples, 16: little-endian u16 samples
+int32_t jxo_image_out_float(const JxoImage* im) { return im->r.out_float ? 1 : 0; }   // bits_out 16 / 32 are binary16 / binary32
 int32_t jxo_image_epf_iters(const JxoImage* im) { return im->r.frame.lf.epf_iters; }
 size_t jxo_image_exif(const JxoImage* im, const uint8_t** p) { *p = im->r.boxes.exif.data(); return im->r.boxes.exif.size(); }
 size_t jxo_image_xml(const JxoImage* im, const uint8_t** p) {
@@ -80,6 +81,7 @@ struct JxoEncodeParams {
   int32_t num_threads;
   int32_t bits;   // bits per sample (8..16); above 8 `px` holds uint16 samples
   int32_t orientation;   // 0 / 1: none; 2..8: EXIF orientation written to the header
+  int32_t float_samples; // 0: integer samples; 16 / 32: `px` holds binary16 (as uint16 bit patterns) / binary32 samples
 };
 
 JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
@@ -94,6 +96,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.num_threads = ep->num_threads;
     p.bits = ep->bits ? ep->bits : 8;
     p.orientation = ep->orientation ? ep->orientation : 1;
+    p.float_samples = ep->float_samples;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

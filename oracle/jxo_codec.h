@@ -32,6 +32,7 @@ struct DecodeResult {
   int num_channels = 0;         // 1,2,3,4 (gray[+a], rgb[+a])
   int out_w = 0, out_h = 0;     // size of `pixels`: the frame size with the header's orientation applied (5..8 swap the sides)
   int bits_out = 8;             // 8: `pixels` holds u8 samples; 16: little-endian u16 samples (streams of more than 8 bits per sample)
+  bool out_float = false;       // float-sample streams: bits_out 16 = binary16, 32 = binary32 (little-endian bit patterns)
   std::vector<uint8_t> pixels;  // interleaved, tight rows
   StageDump dump;
 };
@@ -62,6 +63,7 @@ struct EncodeParams {
   int num_threads = 1;
   int orientation = 1;          // EXIF orientation written to the header (1..8); the pixels handed in are the STORED image
   int bits = 8;                 // bits per sample signalled in the header (8..16); above 8 the input samples are uint16
+  int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
 };
 
 // rgba: interleaved RGBA8 (or RGB8 / Gray8 / GrayA8 according to nch), tight rows.

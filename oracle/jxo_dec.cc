@@ -430,6 +430,69 @@ static uint32_t IntToOut(int32_t v, uint32_t bits, int bits_out) {
   const float f = (float)v * (1.0f / (float)maxv);
   return bits_out == 16 ? ToU16(f) : ToU8(f);
 }
+// IEEE half <-> float (round to nearest even; subnormals kept), the conversions behind the Float16 representation
+static float HalfToFloat(uint32_t h) {
+  const uint32_t sign = (h >> 15) & 1, e = (h >> 10) & 31, mnt = h & 1023;
+  uint32_t u;
+  if (e == 0) {
+    if (mnt == 0) u = sign << 31;
+    else {
+      int shift = 0;
+      uint32_t mm = mnt;
+      while (!(mm & 1024)) { mm <<= 1; shift++; }
+      u = sign << 31 | (uint32_t)(127 - 15 + 1 - shift) << 23 | (mm & 1023) << 13;
+    }
+  } else if (e == 31) u = sign << 31 | 0xFFu << 23 | mnt << 13;
+  else u = sign << 31 | (e - 15 + 127) << 23 | mnt << 13;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+static uint32_t FloatToHalf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint32_t sign = (u >> 16) & 0x8000;
+  const int32_t e = (int32_t)((u >> 23) & 0xFF) - 127 + 15;
+  uint32_t mnt = u & 0x7FFFFF;
+  if (((u >> 23) & 0xFF) == 0xFF) return sign | 0x7C00 | (mnt ? 0x200 : 0);
+  if (e >= 31) return sign | 0x7C00;
+  if (e <= 0) {
+    if (e < -10) return sign;
+    mnt |= 0x800000;
+    const int shift = 14 - e;
+    uint32_t h = mnt >> shift;
+    const uint32_t rem = mnt & ((1u << shift) - 1), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (h & 1))) h++;
+    return sign | h;
+  }
+  uint32_t h = (uint32_t)e << 10 | mnt >> 13;
+  const uint32_t rem = mnt & 0x1FFF;
+  if (rem > 0x1000 || (rem == 0x1000 && (h & 1))) h++;
+  return sign | h;
+}
+// Sample of a float-coded Modular channel: the integer is the bit pattern of the float type (binary32 / binary16 only).
+static float BitsToFloat(int32_t v, uint32_t bits, uint32_t exp_bits) {
+  if (bits == 32 && exp_bits == 8) { float f; memcpy(&f, &v, 4); return f; }
+  JXO_CHECK(bits == 16 && exp_bits == 5, "float samples other than binary32 / binary16 are not supported yet");
+  return HalfToFloat((uint32_t)v & 0xFFFF);
+}
+// One channel sample (integer of `bits` bits, or float bit pattern when exp_bits > 0) -> raw bits of the output sample type
+static uint32_t SampleToOut(int32_t v, uint32_t bits, uint32_t exp_bits, int bits_out, bool out_float) {
+  if (!out_float && !exp_bits) return IntToOut(v, bits, bits_out);
+  const float f = exp_bits ? BitsToFloat(v, bits, exp_bits) : (float)v * (1.0f / (float)((1u << bits) - 1));
+  if (!out_float) return bits_out == 16 ? ToU16(f) : ToU8(f);
+  if (bits_out == 16) return FloatToHalf(f);
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  return u;
+}
+static uint32_t FloatToOut(float v, int bits_out, bool out_float) {
+  if (!out_float) return bits_out == 16 ? ToU16(v) : ToU8(v);
+  if (bits_out == 16) return FloatToHalf(v);
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  return u;
+}
 
 }  // namespace
 
@@ -443,7 +506,8 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   ReadSizeHeader(br, &m.xsize, &m.ysize);
   ReadImageMetadata(br, m);
   JXO_CHECK(!m.color.want_icc, "embedded ICC profiles are not supported yet");
-  JXO_CHECK(m.bits >= 1 && m.bits <= 16 && m.exp_bits == 0, "only integer samples of up to 16 bits are supported yet");
+  JXO_CHECK(m.exp_bits ? ((m.bits == 32 && m.exp_bits == 8) || (m.bits == 16 && m.exp_bits == 5)) : (m.bits >= 1 && m.bits <= 16),
+            "only integer samples of up to 16 bits and binary16 / binary32 float samples are supported yet");
   br.AlignByte();
   FrameHeader& f = out.frame;
   ReadFrameHeader(br, m, f);
@@ -529,13 +593,14 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   const int alpha_ec = m.alpha_index();
   const int nch = ncolor + (alpha_ec >= 0 ? 1 : 0);
   out.num_channels = nch;
-  out.bits_out = m.bits > 8 ? 16 : 8;
+  // output sample type by the colour channels' depth (Decoder/JxlDecoder.cpp:510-556 of the reference)
+  out.out_float = m.exp_bits != 0;
+  out.bits_out = out.out_float ? (m.bits <= 16 ? 16 : 32) : (m.bits > 8 ? 16 : 8);
   const int bpo = out.bits_out / 8;
   out.pixels.assign((size_t)w * h * nch * bpo, 0);
   auto put = [&](int y, int x, int c, uint32_t v) {
     const size_t i = ((size_t)y * w + x) * nch + c;
-    if (bpo == 1) out.pixels[i] = (uint8_t)v;
-    else { out.pixels[2 * i] = (uint8_t)(v & 0xFF); out.pixels[2 * i + 1] = (uint8_t)(v >> 8); }
+    for (int k = 0; k < bpo; k++) out.pixels[(size_t)bpo * i + k] = (uint8_t)(v >> (8 * k));
   };
   if (f.encoding == 0) {
     Plane img[3];
@@ -579,12 +644,12 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
           for (int c = 0; c < 3; c++) {
             float v = img[c].Row(y)[x];
             v = to_srgb ? LinearToSrgb(v) : v;
-            put(y, x, c, bpo == 1 ? ToU8(v) : ToU16(v));
+            put(y, x, c, FloatToOut(v, out.bits_out, out.out_float));
           }
         } else {
           float v = img[1].Row(y)[x];
           v = to_srgb ? LinearToSrgb(v) : v;
-          put(y, x, 0, bpo == 1 ? ToU8(v) : ToU16(v));
+          put(y, x, 0, FloatToOut(v, out.bits_out, out.out_float));
         }
       }
   } else {
@@ -593,7 +658,7 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
       const Channel& ch = d.full.ch[c];
       JXO_CHECK(ch.w == w && ch.h == h, "modular colour channel size");
       for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) put(y, x, c, IntToOut(ch.Row(y)[x], m.bits, out.bits_out));
+        for (int x = 0; x < w; x++) put(y, x, c, SampleToOut(ch.Row(y)[x], m.bits, m.exp_bits, out.bits_out, out.out_float));
     }
   }
   if (alpha_ec >= 0) {
@@ -601,11 +666,13 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     JXO_CHECK(ci < d.full.ch.size(), "alpha channel missing");
     const Channel& ch = d.full.ch[ci];
     JXO_CHECK(ch.w == w && ch.h == h, "alpha channel size");
-    JXO_CHECK(m.ec[alpha_ec].bits >= 1 && m.ec[alpha_ec].bits <= 16 && m.ec[alpha_ec].exp_bits == 0, "only integer alpha of up to 16 bits is supported yet");
+    const ExtraChannelInfo& ae = m.ec[alpha_ec];
+    JXO_CHECK(ae.exp_bits ? ((ae.bits == 32 && ae.exp_bits == 8) || (ae.bits == 16 && ae.exp_bits == 5)) : (ae.bits >= 1 && ae.bits <= 16),
+              "only integer alpha of up to 16 bits and binary16 / binary32 float alpha are supported yet");
     JXO_CHECK(!m.ec[alpha_ec].alpha_associated, "premultiplied alpha is not supported yet");
     if (dump) dump->alpha = ch.d;
     for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) put(y, x, ncolor, IntToOut(ch.Row(y)[x], m.ec[alpha_ec].bits, out.bits_out));
+      for (int x = 0; x < w; x++) put(y, x, ncolor, SampleToOut(ch.Row(y)[x], ae.bits, ae.exp_bits, out.bits_out, out.out_float));
   }
   // ---- orientation: the decoder library behind the reference hands out the image as it is meant to be displayed
   // (keep_orientation is off by default), sides swapped for orientations 5..8

@@ -119,6 +119,24 @@ std::vector<uint8_t> AssembleFrame(const ImageMetadata& m, const FrameHeader& f,
 }
 
 // ------------------------------------------------------------------ VarDCT
+static float HalfBitsToFloat(uint32_t h) {
+  const uint32_t sign = (h >> 15) & 1, e = (h >> 10) & 31, mnt = h & 1023;
+  uint32_t u;
+  if (e == 0) {
+    if (mnt == 0) u = sign << 31;
+    else {
+      int shift = 0;
+      uint32_t mm = mnt;
+      while (!(mm & 1024)) { mm <<= 1; shift++; }
+      u = sign << 31 | (uint32_t)(127 - 15 + 1 - shift) << 23 | (mm & 1023) << 13;
+    }
+  } else if (e == 31) u = sign << 31 | 0xFFu << 23 | mnt << 13;
+  else u = sign << 31 | (e - 15 + 127) << 23 | mnt << 13;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 struct VarDctEncoder {
   const EncodeParams& p;
   ImageMetadata m;
@@ -228,10 +246,21 @@ struct VarDctEncoder {
     has_alpha = nch == 2 || nch == 4;
     // 1. sRGB8 -> linear -> XYB
     Plane img[3] = {Plane(w, h), Plane(w, h), Plane(w, h)};
+    if (has_alpha) alpha.resize((size_t)w * h);
+    if (m.exp_bits) {
+      // float samples (binary32 arrays; binary16 arrays as their uint16 bit patterns): colour goes through the transfer function as
+      // is, alpha is coded losslessly as the bit pattern of its float type
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+          const size_t o = ((size_t)y * w + x) * nch;
+          auto F = [&](int c) -> float { return m.bits == 32 ? ((const float*)px)[o + c] : HalfBitsToFloat(((const uint16_t*)px)[o + c]); };
+          for (int c = 0; c < 3; c++) img[c].Row(y)[x] = SrgbToLinear(F(ncolor == 3 ? c : 0));
+          if (has_alpha) alpha[(size_t)y * w + x] = m.bits == 32 ? ((const int32_t*)px)[o + ncolor] : (int32_t)((const uint16_t*)px)[o + ncolor];
+        }
+    } else {
     const uint32_t maxv = (1u << m.bits) - 1;
     std::vector<float> lut((size_t)maxv + 1);
     for (uint32_t i = 0; i <= maxv; i++) lut[i] = SrgbToLinear((float)i / (float)maxv);
-    if (has_alpha) alpha.resize((size_t)w * h);
     const uint16_t* px16 = (const uint16_t*)px;   // samples above 8 bits arrive as uint16
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
@@ -240,6 +269,7 @@ struct VarDctEncoder {
         for (int c = 0; c < 3; c++) img[c].Row(y)[x] = lut[S(ncolor == 3 ? c : 0)];
         if (has_alpha) alpha[(size_t)y * w + x] = (int32_t)S(ncolor);
       }
+    }
     LinearToXyb(img);
     // 2. approximate inverse of the decoder-side Gaborish: 2*I - K
     if (f.lf.gab) {
@@ -489,12 +519,13 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
         const size_t o = ((size_t)y * w + x) * nch + c;
-        full.ch[c].Row(y)[x] = m.bits > 8 ? (int32_t)((const uint16_t*)px)[o] : (int32_t)px[o];
+        full.ch[c].Row(y)[x] = m.bits == 32 ? ((const int32_t*)px)[o]   // binary32: the bit pattern
+                                            : (m.bits > 8 ? (int32_t)((const uint16_t*)px)[o] : (int32_t)px[o]);
       }
   }
   GroupHeader gh_global;
   gh_global.use_global_tree = true;
-  if (ncolor == 3) ForwardRCT(full, 0, 6);
+  if (ncolor == 3 && !m.exp_bits) ForwardRCT(full, 0, 6);   // float samples are coded as bit patterns: no colour transform on those
   if (p.lossless_squeeze) {
     std::vector<SqueezeParams> sp;
     DefaultSqueezeParams(full, sp);
@@ -577,10 +608,12 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   m.color.color_space = nch >= 3 ? 0 : 1;
   m.color.white_point = 1; m.color.primaries = 1; m.color.tf = 13; m.color.rendering_intent = 0;
   JXO_CHECK(p.bits >= 8 && p.bits <= 16, "bits per sample must be 8..16");
-  m.bits = (uint32_t)p.bits;
+  JXO_CHECK(p.float_samples == 0 || p.float_samples == 16 || p.float_samples == 32, "float samples are binary16 or binary32");
+  m.bits = p.float_samples ? (uint32_t)p.float_samples : (uint32_t)p.bits;
+  m.exp_bits = p.float_samples == 32 ? 8 : (p.float_samples == 16 ? 5 : 0);
   JXO_CHECK(p.orientation >= 1 && p.orientation <= 8, "orientation must be 1..8");
   m.orientation = (uint32_t)p.orientation;
-  if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = (uint32_t)p.bits; }
+  if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; }
   FrameHeader f;
   f.ec_upsampling.assign(m.ec.size(), 1);
   std::vector<uint8_t> frame;

@@ -198,10 +198,10 @@ def load_image(data, fail_at=None):
             return False
         nch = (1 if img.format == "Gray" else 3) + (1 if img.has_transparency else 0)
         n = img.width * img.height * nch
-        if img.channel_representation == 1:   # ImageChannelRepresentation.Uint16
-            img.pixels = np.ctypeslib.as_array(p, shape=(2 * n,)).view(np.uint16).reshape(img.height, img.width, nch).copy()
-        else:
-            img.pixels = np.ctypeslib.as_array(p, shape=(n,)).reshape(img.height, img.width, nch).copy()
+        # ImageChannelRepresentation (Common.h:33-39): Uint8, Uint16, Float16, Float32
+        dt = (np.uint8, np.uint16, np.float16, np.float32)[img.channel_representation]
+        nbytes = n * np.dtype(dt).itemsize
+        img.pixels = np.ctypeslib.as_array(p, shape=(nbytes,)).view(dt).reshape(img.height, img.width, nch).copy()
         img.layer_name = C.string_at(name, nlen - 1).decode("utf-8", "replace") if name and nlen else None
         return True
 

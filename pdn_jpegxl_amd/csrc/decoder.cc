@@ -65,6 +65,9 @@ struct StageTimer {
 
 using namespace jxlhip;
 
+// Bytes per output sample: the sample type follows the colour channels' depth (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32.
+static inline size_t OutBytesPerSample(const ParsedFrame& f) { return f.exp_bits ? (f.bits <= 16 ? 2 : 4) : (f.bits > 8 ? 2 : 1); }
+
 struct JxlHipDecoder {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -424,7 +427,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.alpha32 = ws.Take(4 * (size_t)f.xsize * f.ysize);
     chunk_pix = std::max(chunk_pix, pix);
     l.inv_sigma = ws.Take(4 * cells);
-    l.alpha = ws.Take((size_t)f.xsize * f.ysize * (f.bits > 8 ? 2 : 1));
+    l.alpha = ws.Take((size_t)f.xsize * f.ysize * OutBytesPerSample(f));
     l.lf_end = ws.Take(8);
     if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
     total_lf += f.nlf;
@@ -443,7 +446,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (parse_status[i] != DecoderStatus_Ok || frames[i].orientation == 1) continue;
     const ParsedFrame& f = frames[i];
     if (band_rows > 0) { parse_status[i] = DecoderStatus_DecodeError; parse_msg[i] = "band decode of a frame with an orientation is not supported"; continue; }
-    L[i].orient_tmp = ws.Take((size_t)f.xsize * f.ysize * (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (f.bits > 8 ? 2 : 1));
+    L[i].orient_tmp = ws.Take((size_t)f.xsize * f.ysize * (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * OutBytesPerSample(f));
   }
   // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
   // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
@@ -544,7 +547,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.wt = (f.w8 + 7) / 8; d.ht = (f.h8 + 7) / 8;
     d.xg = f.xg; d.yg = f.yg; d.ng = f.ng; d.xlf = f.xlf; d.ylf = f.ylf; d.nlf = f.nlf;
     d.ncolor = f.ncolor; d.has_alpha = f.alpha_index >= 0; d.nch_out = d.ncolor + d.has_alpha;
-    d.sample_bits = (int32_t)f.bits; d.alpha_bits = d.has_alpha ? (int32_t)f.ec[f.alpha_index].bits : 8; d.out_bits = f.bits > 8 ? 16 : 8;
+    d.sample_bits = (int32_t)f.bits; d.sample_exp = (int32_t)f.exp_bits;
+    d.alpha_bits = d.has_alpha ? (int32_t)f.ec[f.alpha_index].bits : 8; d.alpha_exp = d.has_alpha ? (int32_t)f.ec[f.alpha_index].exp_bits : 0;
+    d.out_bits = 8 * (int32_t)OutBytesPerSample(f); d.out_float = f.exp_bits ? 1 : 0;
     // band: group rows [b0, b1) are output; one more row each side is decoded for the loop-filter halo
     int b0 = 0, b1 = (int)f.yg;
     if (band_rows > 0 && f.encoding == 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
@@ -806,7 +811,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].orientation != 1) {
       const ParsedFrame& f = frames[i];
-      LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (f.bits > 8 ? 2 : 1),
+      LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (int)OutBytesPerSample(f),
                    (int)f.orientation, stream);
     }
   for (int i = 0; i < n; i++)
@@ -987,7 +992,8 @@ DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, JxlHipImageInfo* inf
     info->width = f.orientation >= 5 ? f.ysize : f.xsize; info->height = f.orientation >= 5 ? f.xsize : f.ysize;   // as displayed
     info->has_alpha = f.alpha_index >= 0;
     info->num_channels = f.ncolor + info->has_alpha;
-    info->bytes_per_sample = f.bits > 8 ? 2 : 1;
+    info->bytes_per_sample = (int32_t)OutBytesPerSample(f);
+    info->reserved = f.exp_bits ? 1 : 0;   // float samples
     info->xsize_blocks = f.w8; info->ysize_blocks = f.h8;
     info->num_groups = f.ng; info->num_lf_groups = f.nlf;
     info->epf_iters = f.epf_iters; info->gaborish = f.gab;
@@ -1124,14 +1130,19 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     if ((f.ncolor != 1 && f.ncolor != 3) || black > 1 || alphas > 1) return DecoderStatus_UnsupportedChannelFormat;   // :485-490
     const bool has_alpha = f.alpha_index >= 0;
     if (black) { SetErr(err, "CMYK images are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
-    // sample type by bit depth (Decoder/JxlDecoder.cpp:510-556): float samples are not decoded on the GPU path yet
-    if (f.exp_bits > 0) { SetErr(err, "Floating point samples are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
-    if (f.bits > 16) { SetErr(err, "Unsupported integer bit depth: %u.", f.bits); return DecoderStatus_DecodeError; }   // :551
-    const bool out16 = f.bits > 8;
+    // sample type by bit depth (Decoder/JxlDecoder.cpp:510-556)
+    int rep = ImageChannelRepresentation_Uint8;
+    if (f.exp_bits > 0) {
+      if (f.bits <= 16) rep = ImageChannelRepresentation_Float16;        // :521-525
+      else if (f.bits <= 32) rep = ImageChannelRepresentation_Float32;   // :526-530
+      else { SetErr(err, "Unsupported floating point bit depth: %u.", f.bits); return DecoderStatus_DecodeError; }   // :531-535
+    } else if (f.bits > 8) {
+      if (f.bits > 16) { SetErr(err, "Unsupported integer bit depth: %u.", f.bits); return DecoderStatus_DecodeError; }   // :551
+      rep = ImageChannelRepresentation_Uint16;
+    }
     const bool swap_sides = f.orientation >= 5;   // the host is told the size as displayed
     cb->setBasicInfo((int32_t)(swap_sides ? f.ysize : f.xsize), (int32_t)(swap_sides ? f.xsize : f.ysize),
-                     f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb,
-                     out16 ? ImageChannelRepresentation_Uint16 : ImageChannelRepresentation_Uint8, has_alpha);   // :558
+                     f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb, (ImageChannelRepresentation)rep, has_alpha);   // :558
     // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108)
     {
       const ColorInfo& c = f.color;
@@ -1155,7 +1166,7 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     // ---- pass 2: the frame (Decoder/JxlDecoder.cpp:217-410)
     JxlHipDecoder* dec = ThreadDecoder();
     const int nch = f.ncolor + (has_alpha ? 1 : 0);
-    const size_t bytes = (size_t)f.xsize * f.ysize * nch * (out16 ? 2 : 1);   // tightly packed, :291-313
+    const size_t bytes = (size_t)f.xsize * f.ysize * nch * OutBytesPerSample(f);   // tightly packed, :291-313
     dec->EnsureLoadImageBuffers(bytes);
     uint8_t* const d_out = dec->li_dev;
     uint8_t* const h_out = dec->li_host;   // valid for the duration of the setLayerData call, like the reference's buffer (:291-313)

@@ -65,9 +65,10 @@ struct DevImage {
   int32_t w, h, w8, h8, wp, hp, wt, ht;
   int32_t xg, yg, ng, xlf, ylf, nlf;
   int32_t ncolor, has_alpha, nch_out, to_srgb;
-  // sample depths: the colour channels / the alpha channel as coded (1..16 bits), and the output sample type (8: u8, 16: u16 -
-  // streams of more than 8 bits per sample, reference Decoder/JxlDecoder.cpp:510-556)
-  int32_t sample_bits, alpha_bits, out_bits, pad_bits;
+  // sample depths: the colour channels / the alpha channel as coded (integers of 1..16 bits, binary16 / binary32 floats), and the
+  // output sample type chosen from the colour depth like the reference does (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32
+  int32_t sample_bits, alpha_bits, out_bits, out_float;   // out_float: out_bits 16 / 32 are binary16 / binary32 samples
+  int32_t sample_exp, alpha_exp;                          // exponent bits of float-coded channels (0: integer samples)
   // codestream
   const uint8_t* cs;
   uint64_t cs_size;

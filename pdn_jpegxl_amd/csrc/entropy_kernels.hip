@@ -1296,7 +1296,7 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
   int32_t* plane = im.alpha32 + (size_t)y0 * im.w + x0;
   const int sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
-  if (im.out_bits == 8 && im.alpha_bits == 8) {   // the common case: clamp to u8, packed stores
+  if (im.out_bits == 8 && im.alpha_bits == 8 && !im.alpha_exp) {   // the common case: clamp to u8, packed stores
     uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
     if (d.kind == kChanResid) {
       PredictWaveTiled<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry,
@@ -1320,10 +1320,8 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
   const bool cst = d.kind == kChanConst;
   for (int i = lane; i < gw * gh; i += 64) {
     const size_t o = (size_t)(i / gw) * im.w + (i % gw);
-    const uint32_t v = IntToOutSample(cst ? d.value : plane[o], im.alpha_bits, im.out_bits);
-    const size_t oi = (size_t)y0 * im.w + x0 + o;
-    if (im.out_bits == 16) ((uint16_t*)im.alpha)[oi] = (uint16_t)v;
-    else im.alpha[oi] = (uint8_t)v;
+    const uint32_t v = SampleToOutBits(cst ? d.value : plane[o], im.alpha_bits, im.alpha_exp, im.out_bits, im.out_float);
+    StoreOutSample(im.alpha, (size_t)y0 * im.w + x0 + o, v, im.out_bits);
   }
 }
 
@@ -1542,15 +1540,12 @@ __global__ void modular_out_kernel(const DevImage* imgs) {
       if (bc == 0) { v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; }
       else { v[1] = o[0]; v[2] = o[1]; v[3] = o[2]; }
     }
-    // colour channels carry sample_bits, the alpha channel (last, if any) alpha_bits; output samples are u8 or u16
+    // colour channels carry sample_bits / sample_exp, the alpha channel (last, if any) alpha_bits / alpha_exp
     const int ncol = nch - (im.has_alpha ? 1 : 0);
-    if (im.out_bits == 16) {
-      uint16_t* out = (uint16_t*)im.out + i * nch;
-      for (int c = 0; c < nch; c++) out[c] = (uint16_t)IntToOutSample(v[c], c < ncol ? im.sample_bits : im.alpha_bits, 16);
-    } else {
-      uint8_t* out = im.out + i * nch;
-      for (int c = 0; c < nch; c++) out[c] = (uint8_t)IntToOutSample(v[c], c < ncol ? im.sample_bits : im.alpha_bits, 8);
-    }
+    for (int c = 0; c < nch; c++)
+      StoreOutSample(im.out, i * nch + c,
+                     SampleToOutBits(v[c], c < ncol ? im.sample_bits : im.alpha_bits, c < ncol ? im.sample_exp : im.alpha_exp, im.out_bits, im.out_float),
+                     im.out_bits);
   }
 }
 

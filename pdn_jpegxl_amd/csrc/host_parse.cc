@@ -1309,9 +1309,10 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   ReadFrameHeader(r, f);
   ReadToc(r, f, frame_base);
   if (headers_only) return;
-  if (f.exp_bits != 0 || f.bits < 1 || f.bits > 16) Fail("only integer samples of up to 16 bits are supported yet");
-  if (f.alpha_index >= 0 && (f.ec[f.alpha_index].exp_bits != 0 || f.ec[f.alpha_index].bits < 1 || f.ec[f.alpha_index].bits > 16))
-    Fail("only integer alpha of up to 16 bits is supported yet");
+  auto depth_ok = [](uint32_t bits, uint32_t exp) { return exp ? ((bits == 32 && exp == 8) || (bits == 16 && exp == 5)) : (bits >= 1 && bits <= 16); };
+  if (!depth_ok(f.bits, f.exp_bits)) Fail("only integer samples of up to 16 bits and binary16 / binary32 float samples are supported yet");
+  if (f.alpha_index >= 0 && !depth_ok(f.ec[f.alpha_index].bits, f.ec[f.alpha_index].exp_bits))
+    Fail("only integer alpha of up to 16 bits and binary16 / binary32 float alpha are supported yet");
   // the reference asks for un-premultiplied output (Decoder/JxlDecoder.cpp:233): premultiplied streams would need the division
   if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated) Fail("premultiplied alpha is not supported yet");
   for (auto& e : f.ec) if (e.dim_shift) Fail("subsampled extra channels are not supported yet");

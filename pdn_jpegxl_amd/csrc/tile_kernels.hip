@@ -60,15 +60,9 @@ __device__ __forceinline__ uint8_t ToU8T(float v) {
   return (uint8_t)(v + 0.5f);
 }
 
-__device__ __forceinline__ uint32_t ToU16T(float v) {
-  v *= 65535.0f;
-  if (!(v > 0.f)) return 0;
-  if (v >= 65535.0f) return 65535;
-  return (uint32_t)(v + 0.5f);
-}
 // The alpha plane holds samples of the output type (alpha_finish_kernel scales them): one u8 or u16 load.
 __device__ __forceinline__ uint32_t LoadAlpha(const DevImage& im, size_t i) {
-  return im.out_bits == 16 ? (uint32_t)((const uint16_t*)im.alpha)[i] : (uint32_t)im.alpha[i];
+  return im.out_bits == 8 ? (uint32_t)im.alpha[i] : (im.out_bits == 16 ? (uint32_t)((const uint16_t*)im.alpha)[i] : ((const uint32_t*)im.alpha)[i]);
 }
 // `a`: the pixel's alpha sample (ignored by layouts without alpha), fetched by the caller ahead of the arithmetic
 __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
@@ -79,14 +73,16 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
   if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
-  if (im.out_bits == 16) {   // streams of more than 8 bits per sample: u16 samples (Decoder/JxlDecoder.cpp:536-548)
-    uint16_t* out = (uint16_t*)im.out + o * im.nch_out;
+  if (im.out_bits != 8) {   // u16 above 8 bits per sample, f16 / f32 for float samples (Decoder/JxlDecoder.cpp:510-548); `a` is raw bits
+    const size_t b = o * im.nch_out;
     if (im.ncolor == 3) {
-      out[0] = (uint16_t)ToU16T(r); out[1] = (uint16_t)ToU16T(g); out[2] = (uint16_t)ToU16T(bl);
-      if (im.has_alpha) out[3] = (uint16_t)a;
+      StoreOutSample(im.out, b, FloatToOutBits(r, im.out_bits, im.out_float), im.out_bits);
+      StoreOutSample(im.out, b + 1, FloatToOutBits(g, im.out_bits, im.out_float), im.out_bits);
+      StoreOutSample(im.out, b + 2, FloatToOutBits(bl, im.out_bits, im.out_float), im.out_bits);
+      if (im.has_alpha) StoreOutSample(im.out, b + 3, a, im.out_bits);
     } else {
-      out[0] = (uint16_t)ToU16T(g);
-      if (im.has_alpha) out[1] = (uint16_t)a;
+      StoreOutSample(im.out, b, FloatToOutBits(g, im.out_bits, im.out_float), im.out_bits);
+      if (im.has_alpha) StoreOutSample(im.out, b + 1, a, im.out_bits);
     }
     return;
   }

@@ -71,5 +71,7 @@ def decode_frame_sharded(dec, data, dst=0):
     if img is None:
         return None
     if info.bytes_per_sample == 2:
-        img = img.view(torch.int16)   # torch has no uint16 arithmetic; callers reinterpret
+        img = img.view(torch.float16 if info.reserved else torch.int16)   # torch has no uint16 arithmetic; callers reinterpret
+    elif info.bytes_per_sample == 4:
+        img = img.view(torch.float32)
     return img.reshape(info.height, info.width, info.num_channels)

@@ -131,3 +131,38 @@ def test_mixed_batch_of_formats(oracle):
         d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
         assert d.max() <= (48 if i.bytes_per_sample == 2 else 1), (d.max(), i.bytes_per_sample)
     dec.close()
+
+
+def _float_image(w, h, seed):
+    rng = np.random.default_rng(seed)
+    img = synth(w, h, seed).astype(np.float32) / 255
+    img = (img + rng.uniform(0, 1e-3, img.shape)).astype(np.float32)
+    img[0, 0, :3] = [1.5, 0.0, 0.75]   # out-of-range samples survive float types
+    return img
+
+
+@pytest.mark.parametrize("kind", [32, 16])
+def test_float_samples_lossless(oracle, kind):
+    """Float-sample streams: Float32 / Float16 representation (Decoder/JxlDecoder.cpp:512-535), samples are the coded bit patterns."""
+    img = _float_image(200, 150, 31)
+    px = img if kind == 32 else img.astype(np.float16)
+    data = oracle.encode(px, lossless=True, float_samples=kind, lossless_predictor=5, lossless_tree=1)
+    got = api.load_image(data)
+    assert got.channel_representation == (3 if kind == 32 else 2) and got.pixels.dtype == px.dtype
+    bits = np.uint32 if kind == 32 else np.uint16
+    assert np.array_equal(got.pixels.view(bits), px.view(bits))                      # ground truth: lossless, bit patterns
+    assert np.array_equal(got.pixels.view(bits), oracle.decode(data).pixels.view(bits))
+
+
+@pytest.mark.parametrize("kind", [32, 16])
+def test_float_samples_lossy(oracle, kind):
+    img = _float_image(300, 260, 32)
+    px = img if kind == 32 else img.astype(np.float16)
+    data = oracle.encode(px, distance=1.0, float_samples=kind)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.pixels.dtype == ref.pixels.dtype == px.dtype
+    d = np.abs(got.pixels[..., :3].astype(np.float32) - ref.pixels[..., :3].astype(np.float32))
+    assert d.max() < (1e-3 if kind == 32 else 2e-3)                                  # float32 summation order / half rounding
+    bits = np.uint32 if kind == 32 else np.uint16
+    assert np.array_equal(got.pixels[..., 3].view(bits), px[..., 3].view(bits))      # alpha is coded losslessly
+    assert np.abs(got.pixels[..., :3].astype(np.float32) - img[..., :3]).mean() < 6 / 255

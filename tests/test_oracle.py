@@ -177,3 +177,20 @@ def test_orientation_against_numpy(oracle):
     for o, f in ops.items():
         d = oracle.decode(oracle.encode(img, lossless=True, orientation=o)).pixels
         assert np.array_equal(d, f(base)), o
+
+
+@pytest.mark.parametrize("kind", [32, 16])
+def test_float_samples_round_trip(oracle, kind):
+    """binary32 / binary16 sample streams: lossless is the identity on the bit patterns (non-negative samples; the integer
+    predictor arithmetic of bit patterns that differ by 2^31 and more - sign changes of binary32 - is outside the tested range)."""
+    rng = np.random.default_rng(kind)
+    img = (synth(90, 70, 5).astype(np.float32) / 255 + rng.uniform(0, 1e-3, (70, 90, 4))).astype(np.float32)
+    img[0, 0, :3] = [1.5, 0.0, 0.75]
+    px = img if kind == 32 else img.astype(np.float16)
+    bits = np.uint32 if kind == 32 else np.uint16
+    d = oracle.decode(oracle.encode(px, lossless=True, float_samples=kind, lossless_predictor=5, lossless_tree=1))
+    assert d.pixels.dtype == px.dtype and np.array_equal(d.pixels.view(bits), px.view(bits))
+    d = oracle.decode(oracle.encode(px, distance=1.0, float_samples=kind))
+    assert d.pixels.dtype == px.dtype
+    assert np.abs(d.pixels[..., :3].astype(np.float32) - img[..., :3]).mean() < 6 / 255
+    assert np.array_equal(d.pixels[..., 3].view(bits), px[..., 3].view(bits))

@@ -82,6 +82,7 @@ struct JxoEncodeParams {
   int32_t bits;   // bits per sample (8..16); above 8 `px` holds uint16 samples
   int32_t orientation;   // 0 / 1: none; 2..8: EXIF orientation written to the header
   int32_t float_samples; // 0: integer samples; 16 / 32: `px` holds binary16 (as uint16 bit patterns) / binary32 samples
+  int32_t colour;        // EncodeParams::colour
 };
 
 JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
@@ -97,6 +98,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.bits = ep->bits ? ep->bits : 8;
     p.orientation = ep->orientation ? ep->orientation : 1;
     p.float_samples = ep->float_samples;
+    p.colour = ep->colour;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

@@ -247,6 +247,8 @@ struct VarDctEncoder {
     // 1. sRGB8 -> linear -> XYB
     Plane img[3] = {Plane(w, h), Plane(w, h), Plane(w, h)};
     if (has_alpha) alpha.resize((size_t)w * h);
+    const int tfk = TransferKind(m.color);
+    JXO_CHECK(tfk >= 0, "transfer function");
     if (m.exp_bits) {
       // float samples (binary32 arrays; binary16 arrays as their uint16 bit patterns): colour goes through the transfer function as
       // is, alpha is coded losslessly as the bit pattern of its float type
@@ -254,13 +256,13 @@ struct VarDctEncoder {
         for (int x = 0; x < w; x++) {
           const size_t o = ((size_t)y * w + x) * nch;
           auto F = [&](int c) -> float { return m.bits == 32 ? ((const float*)px)[o + c] : HalfBitsToFloat(((const uint16_t*)px)[o + c]); };
-          for (int c = 0; c < 3; c++) img[c].Row(y)[x] = SrgbToLinear(F(ncolor == 3 ? c : 0));
+          for (int c = 0; c < 3; c++) img[c].Row(y)[x] = DecodeTransfer(tfk, F(ncolor == 3 ? c : 0), m.intensity_target);
           if (has_alpha) alpha[(size_t)y * w + x] = m.bits == 32 ? ((const int32_t*)px)[o + ncolor] : (int32_t)((const uint16_t*)px)[o + ncolor];
         }
     } else {
     const uint32_t maxv = (1u << m.bits) - 1;
     std::vector<float> lut((size_t)maxv + 1);
-    for (uint32_t i = 0; i <= maxv; i++) lut[i] = SrgbToLinear((float)i / (float)maxv);
+    for (uint32_t i = 0; i <= maxv; i++) lut[i] = DecodeTransfer(tfk, (float)i / (float)maxv, m.intensity_target);
     const uint16_t* px16 = (const uint16_t*)px;   // samples above 8 bits arrive as uint16
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
@@ -269,6 +271,25 @@ struct VarDctEncoder {
         for (int c = 0; c < 3; c++) img[c].Row(y)[x] = lut[S(ncolor == 3 ? c : 0)];
         if (has_alpha) alpha[(size_t)y * w + x] = (int32_t)S(ncolor);
       }
+    }
+    {
+      // linear RGB of the image's primaries, relative to the intensity target -> linear sRGB relative to 255 nits (what XYB is built on)
+      double conv[9], inv[9];
+      JXO_CHECK(MatrixFromSrgb(ncolor == 3 ? m.color.primaries : 1, conv), "primaries");
+      const double d = conv[0] * (conv[4] * conv[8] - conv[5] * conv[7]) - conv[1] * (conv[3] * conv[8] - conv[5] * conv[6]) +
+                       conv[2] * (conv[3] * conv[7] - conv[4] * conv[6]);
+      inv[0] = (conv[4] * conv[8] - conv[5] * conv[7]) / d; inv[1] = (conv[2] * conv[7] - conv[1] * conv[8]) / d; inv[2] = (conv[1] * conv[5] - conv[2] * conv[4]) / d;
+      inv[3] = (conv[5] * conv[6] - conv[3] * conv[8]) / d; inv[4] = (conv[0] * conv[8] - conv[2] * conv[6]) / d; inv[5] = (conv[2] * conv[3] - conv[0] * conv[5]) / d;
+      inv[6] = (conv[3] * conv[7] - conv[4] * conv[6]) / d; inv[7] = (conv[1] * conv[6] - conv[0] * conv[7]) / d; inv[8] = (conv[0] * conv[4] - conv[1] * conv[3]) / d;
+      const double sc = m.intensity_target / 255.0;
+      const bool ident = m.color.primaries == 1 && sc == 1.0;
+      if (!ident)
+        for (size_t i = 0; i < img[0].d.size(); i++) {
+          const double r = img[0].d[i], g = img[1].d[i], b = img[2].d[i];
+          img[0].d[i] = (float)((inv[0] * r + inv[1] * g + inv[2] * b) * sc);
+          img[1].d[i] = (float)((inv[3] * r + inv[4] * g + inv[5] * b) * sc);
+          img[2].d[i] = (float)((inv[6] * r + inv[7] * g + inv[8] * b) * sc);
+        }
     }
     LinearToXyb(img);
     // 2. approximate inverse of the decoder-side Gaborish: 2*I - K
@@ -607,6 +628,16 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   m.color.all_default = false;
   m.color.color_space = nch >= 3 ? 0 : 1;
   m.color.white_point = 1; m.color.primaries = 1; m.color.tf = 13; m.color.rendering_intent = 0;
+  switch (p.colour) {
+    case 0: break;
+    case 1: m.color.primaries = 11; break;
+    case 2: m.color.tf = 1; break;
+    case 3: m.color.primaries = 9; m.color.tf = 8; break;
+    case 4: m.color.primaries = 9; m.color.tf = 16; m.intensity_target = 10000.f; break;
+    case 5: m.color.tf = 8; break;
+    default: JXO_CHECK(false, "unknown colour option");
+  }
+  if (nch < 3) m.color.primaries = 1;   // gray: no primaries
   JXO_CHECK(p.bits >= 8 && p.bits <= 16, "bits per sample must be 8..16");
   JXO_CHECK(p.float_samples == 0 || p.float_samples == 16 || p.float_samples == 32, "float samples are binary16 or binary32");
   m.bits = p.float_samples ? (uint32_t)p.float_samples : (uint32_t)p.bits;

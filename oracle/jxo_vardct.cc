@@ -816,8 +816,18 @@ void Epf(Plane xyb[3], const LoopFilter& lf, const Plane& inv_sigma) {
 
 // ------------------------------------------------------------------ colour
 void XybToLinear(const ImageMetadata& m, Plane xyb[3]) {
+  // linear RGB of the image's own primaries: the change of primaries is folded into the inverse opsin matrix
+  double conv[9];
+  const uint32_t prim = m.color.all_default ? 1 : m.color.primaries;
+  JXO_CHECK(m.color.color_space == 1 || MatrixFromSrgb(prim, conv), "only sRGB / P3 / BT.2100 primaries are supported yet");
+  if (m.color.color_space == 1) MatrixFromSrgb(1, conv);
   float inv[9];
-  for (int i = 0; i < 9; i++) inv[i] = m.opsin_inverse[i] * (255.0f / m.intensity_target);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) {
+      double a = 0;
+      for (int k = 0; k < 3; k++) a += conv[r * 3 + k] * (double)m.opsin_inverse[k * 3 + c];
+      inv[r * 3 + c] = (float)a * (255.0f / m.intensity_target);
+    }
   float bias[3], cb[3];
   for (int i = 0; i < 3; i++) { bias[i] = m.opsin_bias[i]; cb[i] = std::cbrt(bias[i]); }
   size_t n = xyb[0].d.size();
@@ -849,13 +859,95 @@ void LinearToXyb(Plane rgb[3]) {
   }
 }
 
-float LinearToSrgb(float v) {
-  if (v <= 0.0031308f) return 12.92f * v;
-  return 1.055f * std::pow(v, 1.0f / 2.4f) - 0.055f;
+float LinearToSrgb(float v) {   // sign-symmetric
+  const float a = std::fabs(v);
+  const float r = a <= 0.0031308f ? 12.92f * a : 1.055f * std::pow(a, 1.0f / 2.4f) - 0.055f;
+  return std::copysign(r, v);
 }
 float SrgbToLinear(float v) {
-  if (v <= 0.04045f) return v / 12.92f;
-  return std::pow((v + 0.055f) / 1.055f, 2.4f);
+  const float a = std::fabs(v);
+  const float r = a <= 0.04045f ? a / 12.92f : std::pow((a + 0.055f) / 1.055f, 2.4f);
+  return std::copysign(r, v);
+}
+
+int TransferKind(const ColorEncoding& c) {
+  if (c.all_default) return 1;
+  if (c.have_gamma) return -1;
+  switch (c.tf) {
+    case 8: return 0;
+    case 13: return 1;
+    case 1: return 2;
+    case 16: return 3;
+    default: return -1;
+  }
+}
+static const float kPqM1 = 0.1593017578125f, kPqM2 = 78.84375f, kPqC1 = 0.8359375f, kPqC2 = 18.8515625f, kPqC3 = 18.6875f;
+float EncodeTransfer(int kind, float v, float intensity_target) {
+  const float a = std::fabs(v);
+  float r;
+  switch (kind) {
+    case 1: return LinearToSrgb(v);
+    case 2: r = a < 0.018f ? 4.5f * a : 1.099f * std::pow(a, 0.45f) - 0.099f; break;
+    case 3: {
+      const float xp = std::pow(a * (intensity_target * 1e-4f), kPqM1);
+      r = std::pow((kPqC1 + kPqC2 * xp) / (1.0f + kPqC3 * xp), kPqM2);
+      if (a == 0.f) r = 0.f;   // the curve's value at 0 is 7.3e-7: keep black black
+      break;
+    }
+    default: return v;
+  }
+  return std::copysign(r, v);
+}
+float DecodeTransfer(int kind, float e, float intensity_target) {
+  const float a = std::fabs(e);
+  float r;
+  switch (kind) {
+    case 1: return SrgbToLinear(e);
+    case 2: r = a < 0.081f ? a / 4.5f : std::pow((a + 0.099f) / 1.099f, 1.0f / 0.45f); break;
+    case 3: {
+      const float xp = std::pow(a, 1.0f / kPqM2);
+      const float num = std::max(xp - kPqC1, 0.0f), den = kPqC2 - kPqC3 * xp;
+      r = std::pow(num / den, 1.0f / kPqM1) * (1e4f / intensity_target);
+      break;
+    }
+    default: return e;
+  }
+  return std::copysign(r, e);
+}
+
+static void Inv3(const double m[9], double o[9]) {
+  const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  o[0] = (m[4] * m[8] - m[5] * m[7]) / d; o[1] = (m[2] * m[7] - m[1] * m[8]) / d; o[2] = (m[1] * m[5] - m[2] * m[4]) / d;
+  o[3] = (m[5] * m[6] - m[3] * m[8]) / d; o[4] = (m[0] * m[8] - m[2] * m[6]) / d; o[5] = (m[2] * m[3] - m[0] * m[5]) / d;
+  o[6] = (m[3] * m[7] - m[4] * m[6]) / d; o[7] = (m[1] * m[6] - m[0] * m[7]) / d; o[8] = (m[0] * m[4] - m[1] * m[3]) / d;
+}
+// RGB -> XYZ of a set of primaries with a D65 white point, from the chromaticities
+static void RgbToXyz(const double xy[3][2], double m[9]) {
+  const double wx = 0.3127, wy = 0.3290;
+  double p[9];
+  for (int c = 0; c < 3; c++) { p[c] = xy[c][0] / xy[c][1]; p[3 + c] = 1.0; p[6 + c] = (1.0 - xy[c][0] - xy[c][1]) / xy[c][1]; }
+  double pi[9];
+  Inv3(p, pi);
+  const double W[3] = {wx / wy, 1.0, (1.0 - wx - wy) / wy};
+  for (int c = 0; c < 3; c++) {
+    const double sc = pi[c * 3] * W[0] + pi[c * 3 + 1] * W[1] + pi[c * 3 + 2] * W[2];
+    for (int r = 0; r < 3; r++) m[r * 3 + c] = p[r * 3 + c] * sc;
+  }
+}
+bool MatrixFromSrgb(uint32_t primaries, double out[9]) {
+  static const double kSrgb[3][2] = {{0.639998686, 0.330010138}, {0.300003784, 0.600003357}, {0.150002046, 0.059997204}};
+  static const double kP3[3][2] = {{0.680, 0.320}, {0.265, 0.690}, {0.150, 0.060}};
+  static const double k2100[3][2] = {{0.708, 0.292}, {0.170, 0.797}, {0.131, 0.046}};
+  const double (*t)[2] = primaries == 1 ? kSrgb : (primaries == 11 ? kP3 : (primaries == 9 ? k2100 : nullptr));
+  if (!t) return false;
+  if (primaries == 1) { for (int i = 0; i < 9; i++) out[i] = (i % 4 == 0) ? 1.0 : 0.0; return true; }
+  double ms[9], mt[9], mti[9];
+  RgbToXyz(kSrgb, ms);
+  RgbToXyz(t, mt);
+  Inv3(mt, mti);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) out[r * 3 + c] = mti[r * 3] * ms[c] + mti[r * 3 + 1] * ms[3 + c] + mti[r * 3 + 2] * ms[6 + c];
+  return true;
 }
 
 }  // namespace jxo

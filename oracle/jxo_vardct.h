@@ -68,6 +68,14 @@ void XybToLinear(const ImageMetadata& m, Plane xyb[3]);   // in place: X,Y,B -> 
 void LinearToXyb(Plane rgb[3]);                            // in place
 float LinearToSrgb(float v);
 float SrgbToLinear(float v);
+// Enumerated colour encodings the reference's host knows by name (Decoder/JxlDecoder.cpp:36-108): D65, primaries sRGB / P3 /
+// BT.2100, transfer linear / sRGB / BT.709 / PQ.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ; -1: not one of those.
+int TransferKind(const ColorEncoding& c);
+// Encoded value from display-linear (sign-symmetric like the reference's library); PQ takes the image's intensity target.
+float EncodeTransfer(int kind, float v, float intensity_target);
+float DecodeTransfer(int kind, float e, float intensity_target);
+// 3x3 (row-major) linear sRGB -> linear RGB of the primaries (1 sRGB: identity, 9 BT.2100, 11 P3); false: other primaries.
+bool MatrixFromSrgb(uint32_t primaries, double out[9]);
 
 // Block-context map (HfBlockContext) of LfGlobal.
 struct BlockCtxMap {

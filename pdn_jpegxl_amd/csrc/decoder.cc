@@ -555,7 +555,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (band_rows > 0 && f.encoding == 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
     d.dec_gy0 = std::max(0, b0 - 1); d.dec_gy1 = std::min<int>((int)f.yg, b1 + 1);
     d.band_y0 = std::min<int>(b0 * kGroupDim, (int)f.ysize); d.band_y1 = std::min<int>(b1 * kGroupDim, (int)f.ysize);
-    d.to_srgb = f.color.all_default || (!f.color.have_gamma && f.color.tf == 13);
+    const ColorPlan plan = PlanColor(f);
+    d.to_srgb = plan.transfer;   // 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+    d.pq_scale = f.intensity_target * 1e-4f;
     auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h_blob + off, src, bytes); };
     put(l.sec_off, f.sec_off.data(), 8 * f.sec_off.size());
     put(l.sec_size, f.sec_size.data(), 4 * f.sec_size.size());
@@ -663,7 +665,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     memcpy(d.epf_channel_scale, f.epf_channel_scale, sizeof(d.epf_channel_scale));
     d.epf_quant_mul = f.epf_quant_mul; d.epf_pass0_sigma_scale = f.epf_pass0_sigma_scale;
     d.epf_pass2_sigma_scale = f.epf_pass2_sigma_scale; d.epf_border_sad_mul = f.epf_border_sad_mul;
-    for (int k = 0; k < 9; k++) d.opsin_inv[k] = f.opsin_inv[k] * (255.0f / f.intensity_target);
+    // linear RGB of the image's own primaries, relative to its intensity target: change of primaries folded into the inverse opsin matrix
+    for (int r = 0; r < 3; r++)
+      for (int k = 0; k < 3; k++) {
+        double a = 0;
+        for (int j = 0; j < 3; j++) a += (double)plan.from_srgb[r * 3 + j] * (double)f.opsin_inv[j * 3 + k];
+        d.opsin_inv[r * 3 + k] = (float)a * (255.0f / f.intensity_target);
+      }
     for (int k = 0; k < 3; k++) { d.opsin_bias[k] = f.opsin_bias[k]; d.opsin_bias_cbrt[k] = std::cbrt(f.opsin_bias[k]); }
     // planes
     d.cellinfo = (uint32_t*)(wz + l.z_cellinfo);
@@ -1143,21 +1151,10 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     const bool swap_sides = f.orientation >= 5;   // the host is told the size as displayed
     cb->setBasicInfo((int32_t)(swap_sides ? f.ysize : f.xsize), (int32_t)(swap_sides ? f.xsize : f.ysize),
                      f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb, (ImageChannelRepresentation)rep, has_alpha);   // :558
-    // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108)
+    // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108); anything else would take the reference's ICC route
     {
-      const ColorInfo& c = f.color;
-      int prof = -1;
-      const uint32_t tf = c.all_default ? 13 : c.tf, wp = c.all_default ? 1 : c.white_point, pr = c.all_default ? 1 : c.primaries;
-      if (!c.have_gamma && wp == 1) {
-        if (f.ncolor == 3) {
-          if (tf == 8 && pr == 1) prof = KnownColorProfile_LinearSrgb;
-          else if (tf == 13 && pr == 1) prof = KnownColorProfile_Srgb;
-        } else {
-          if (tf == 8) prof = KnownColorProfile_LinearGray;
-          else if (tf == 13) prof = KnownColorProfile_GraySrgbTRC;
-        }
-      }
-      if (prof < 0) { SetErr(err, "Colour encoding is not supported on the GPU path yet (only sRGB / linear sRGB / gray)."); return DecoderStatus_DecodeError; }
+      const int prof = PlanColor(f).known_profile;
+      if (prof < 0) { SetErr(err, "This colour encoding needs an ICC profile, which the GPU path does not build yet."); return DecoderStatus_DecodeError; }
       if (!cb->setKnownColorProfile((KnownColorProfile)prof)) return DecoderStatus_CreateMetadataError;   // :648-651
     }
     if (f.exif && f.exif_size && !cb->setExif(const_cast<uint8_t*>(f.exif), f.exif_size)) return DecoderStatus_CreateMetadataError;   // :764

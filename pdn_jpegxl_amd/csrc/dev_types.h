@@ -64,7 +64,8 @@ struct DevImage {
   // geometry
   int32_t w, h, w8, h8, wp, hp, wt, ht;
   int32_t xg, yg, ng, xlf, ylf, nlf;
-  int32_t ncolor, has_alpha, nch_out, to_srgb;
+  int32_t ncolor, has_alpha, nch_out, to_srgb;   // to_srgb: transfer function of the output, 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+  float pq_scale, pad_color;                     // intensity target / 10000 (PQ)
   // sample depths: the colour channels / the alpha channel as coded (integers of 1..16 bits, binary16 / binary32 floats), and the
   // output sample type chosen from the colour depth like the reference does (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32
   int32_t sample_bits, alpha_bits, out_bits, out_float;   // out_float: out_bits 16 / 32 are binary16 / binary32 samples

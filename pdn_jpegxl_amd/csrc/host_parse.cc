@@ -1,6 +1,7 @@
 // Host-side frame parser (see host_parse.h).  Restates ISO/IEC 18181-1 header syntax; the
 // reference reaches it via libjxl (Decoder/JxlDecoder.cpp:454 JxlDecoderProcessInput).
 #include "host_parse.h"
+#include "../../include/jxlfiletypeio.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -1203,6 +1204,60 @@ void SplitContainer(const uint8_t* data, size_t size, ParsedFrame& f) {
 
 }  // namespace
 
+// ------------------------------------------------------------------ colour encodings
+namespace {
+void Inv3(const double m[9], double o[9]) {
+  const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+  o[0] = (m[4] * m[8] - m[5] * m[7]) / d; o[1] = (m[2] * m[7] - m[1] * m[8]) / d; o[2] = (m[1] * m[5] - m[2] * m[4]) / d;
+  o[3] = (m[5] * m[6] - m[3] * m[8]) / d; o[4] = (m[0] * m[8] - m[2] * m[6]) / d; o[5] = (m[2] * m[3] - m[0] * m[5]) / d;
+  o[6] = (m[3] * m[7] - m[4] * m[6]) / d; o[7] = (m[1] * m[6] - m[0] * m[7]) / d; o[8] = (m[0] * m[4] - m[1] * m[3]) / d;
+}
+// RGB -> XYZ of a set of primaries with a D65 white point, from the chromaticities
+void RgbToXyz(const double xy[3][2], double m[9]) {
+  const double wx = 0.3127, wy = 0.3290;
+  double p[9], pi[9];
+  for (int c = 0; c < 3; c++) { p[c] = xy[c][0] / xy[c][1]; p[3 + c] = 1.0; p[6 + c] = (1.0 - xy[c][0] - xy[c][1]) / xy[c][1]; }
+  Inv3(p, pi);
+  const double W[3] = {wx / wy, 1.0, (1.0 - wx - wy) / wy};
+  for (int c = 0; c < 3; c++) {
+    const double sc = pi[c * 3] * W[0] + pi[c * 3 + 1] * W[1] + pi[c * 3 + 2] * W[2];
+    for (int r = 0; r < 3; r++) m[r * 3 + c] = p[r * 3 + c] * sc;
+  }
+}
+}  // namespace
+
+// The enumerated encodings the reference's host knows by name; everything else would take its ICC route.  XYB decodes to linear
+// sRGB; other primaries are a 3x3 matrix on the linear values (folded into the inverse opsin matrix by the caller).
+ColorPlan PlanColor(const ParsedFrame& f) {
+  ColorPlan p;
+  const ColorInfo& c = f.color;
+  const uint32_t tf = c.all_default ? 13 : c.tf, wp = c.all_default ? 1 : c.white_point, pr = c.all_default ? 1 : c.primaries;
+  const uint32_t cs = c.all_default ? 0 : c.color_space;
+  if (c.want_icc || c.have_gamma || wp != 1) return p;
+  p.transfer = tf == 8 ? 0 : (tf == 13 ? 1 : (tf == 1 ? 2 : (tf == 16 ? 3 : -1)));
+  if (cs == 0) {   // RGB, D65 (Decoder/JxlDecoder.cpp:42-88)
+    if (tf == 8) p.known_profile = pr == 1 ? KnownColorProfile_LinearSrgb : (pr == 9 ? KnownColorProfile_Rec2020Linear : -1);
+    else if (tf == 13) p.known_profile = pr == 1 ? KnownColorProfile_Srgb : (pr == 11 ? KnownColorProfile_DisplayP3 : -1);
+    else if (tf == 1) p.known_profile = pr == 1 ? KnownColorProfile_Rec709 : -1;
+    else if (pr == 9 && tf == 16) p.known_profile = KnownColorProfile_Rec2020PQ;
+  } else if (cs == 1) {   // gray, D65 (:90-104)
+    if (tf == 8) p.known_profile = KnownColorProfile_LinearGray;
+    else if (tf == 13) p.known_profile = KnownColorProfile_GraySrgbTRC;
+  }
+  if (p.known_profile >= 0 && cs == 0 && pr != 1) {
+    static const double kSrgb[3][2] = {{0.639998686, 0.330010138}, {0.300003784, 0.600003357}, {0.150002046, 0.059997204}};
+    static const double kP3[3][2] = {{0.680, 0.320}, {0.265, 0.690}, {0.150, 0.060}};
+    static const double k2100[3][2] = {{0.708, 0.292}, {0.170, 0.797}, {0.131, 0.046}};
+    double ms[9], mt[9], mti[9];
+    RgbToXyz(kSrgb, ms);
+    RgbToXyz(pr == 11 ? kP3 : k2100, mt);
+    Inv3(mt, mti);
+    for (int r = 0; r < 3; r++)
+      for (int k = 0; k < 3; k++) p.from_srgb[r * 3 + k] = (float)(mti[r * 3] * ms[k] + mti[r * 3 + 1] * ms[3 + k] + mti[r * 3 + 2] * ms[6 + k]);
+  }
+  return p;
+}
+
 void BuildAliasTable(const std::vector<int>& counts, uint32_t log_alpha, uint64_t* out) { BuildAlias(counts, log_alpha, out); }
 
 // Test hooks for the encoder's host writers (CPU tests): read back what host_write.cc wrote with the decoder's own readers.
@@ -1316,6 +1371,8 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   // the reference asks for un-premultiplied output (Decoder/JxlDecoder.cpp:233): premultiplied streams would need the division
   if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated) Fail("premultiplied alpha is not supported yet");
   for (auto& e : f.ec) if (e.dim_shift) Fail("subsampled extra channels are not supported yet");
+  if (PlanColor(f).known_profile < 0)
+    Fail("colour encodings other than D65 sRGB / linear sRGB / Display P3 / BT.709 / BT.2020 linear / BT.2020 PQ / gray need an ICC profile, which is not built yet");
   if (f.encoding == 0 && !f.xyb_encoded) Fail("VarDCT frames without XYB are not supported yet");
   if (f.encoding == 1 && f.xyb_encoded) Fail("lossy Modular (XYB) frames are not decoded on the GPU path yet");
   if (f.encoding == 1 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u)) Fail("extra channels other than alpha are not supported yet");

@@ -48,6 +48,15 @@ struct ColorInfo {
 
 struct ExtraChannel { uint32_t type = 0, bits = 8, exp_bits = 0, dim_shift = 0; bool alpha_associated = false; };
 
+// What the colour encoding of a stream means for the decode (reference: SetProfileFromColorEncoding, Decoder/JxlDecoder.cpp:36-108).
+struct ColorPlan {
+  int known_profile = -1;   // KnownColorProfile the host is told, -1: an encoding the host would need an ICC profile for (not built)
+  int transfer = 1;         // 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+  float from_srgb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // linear sRGB -> linear RGB of the image's primaries (row-major)
+};
+struct ParsedFrame;
+ColorPlan PlanColor(const ParsedFrame& f);
+
 struct ParsedFrame {
   // ---- container
   bool is_container = false;

@@ -50,8 +50,19 @@ __device__ __forceinline__ int Mirror(int v, int n) {
 
 // v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
 // * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
-__device__ __forceinline__ float SrgbOetfT(float v) {
-  return v <= 0.0031308f ? 12.92f * v : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
+__device__ __forceinline__ float PowT(float a, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * e); }   // a > 0
+// Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ.
+__device__ __forceinline__ float EncodeTransferT(int kind, float v, float pq_scale) {
+  if (kind == 0) return v;
+  const float a = fabsf(v);
+  float r;
+  if (kind == 1) r = a <= 0.0031308f ? 12.92f * a : 1.055f * PowT(a, 1.0f / 2.4f) - 0.055f;
+  else if (kind == 2) r = a < 0.018f ? 4.5f * a : 1.099f * PowT(a, 0.45f) - 0.099f;
+  else {
+    const float xp = a > 0.f ? PowT(a * pq_scale, 0.1593017578125f) : 0.f;
+    r = a > 0.f ? PowT((0.8359375f + 18.8515625f * xp) / (1.0f + 18.6875f * xp), 78.84375f) : 0.f;
+  }
+  return copysignf(r, v);
 }
 __device__ __forceinline__ uint8_t ToU8T(float v) {
   v *= 255.0f;
@@ -71,7 +82,7 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
   float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
   float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
-  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
+  if (im.to_srgb) { r = EncodeTransferT(im.to_srgb, r, im.pq_scale); g = EncodeTransferT(im.to_srgb, g, im.pq_scale); bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale); }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.out_bits != 8) {   // u16 above 8 bits per sample, f16 / f32 for float samples (Decoder/JxlDecoder.cpp:510-548); `a` is raw bits
     const size_t b = o * im.nch_out;

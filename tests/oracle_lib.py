@@ -12,7 +12,7 @@ class EncodeParams(C.Structure):
     _fields_ = [("distance", C.c_float), ("lossless", C.c_int32), ("effort", C.c_int32), ("strategy_mode", C.c_int32),
                 ("fixed_strategy", C.c_int32), ("seed", C.c_uint32), ("epf_iters", C.c_int32), ("gaborish", C.c_int32),
                 ("container", C.c_int32), ("adaptive_lf_smoothing", C.c_int32), ("lossless_predictor", C.c_int32),
-                ("lossless_squeeze", C.c_int32), ("lossless_tree", C.c_int32), ("num_threads", C.c_int32), ("bits", C.c_int32), ("orientation", C.c_int32), ("float_samples", C.c_int32)]
+                ("lossless_squeeze", C.c_int32), ("lossless_tree", C.c_int32), ("num_threads", C.c_int32), ("bits", C.c_int32), ("orientation", C.c_int32), ("float_samples", C.c_int32), ("colour", C.c_int32)]
 
 
 def build():
@@ -60,7 +60,7 @@ class OracleError(RuntimeError):
 
 def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, seed=1, epf_iters=-1, gaborish=True,
            container=True, adaptive_lf_smoothing=True, lossless_predictor=6, lossless_squeeze=False, num_threads=8, exif=None,
-           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0):
+           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0):
     """px: uint8 array (h, w, nch) with nch in 1..4 (Gray, GrayA, RGB, RGBA); with bits > 8 (up to 16) a uint16 array whose
     samples use the low `bits` bits; with float_samples = 16 / 32 a float16 / float32 array (nominal range [0, 1]).  Returns bytes."""
     L = lib()
@@ -72,7 +72,7 @@ def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, 
         px = px[:, :, None]
     h, w, nch = px.shape
     p = EncodeParams(distance, int(lossless), 7, strategy_mode, fixed_strategy, seed, epf_iters, int(gaborish), int(container),
-                     int(adaptive_lf_smoothing), lossless_predictor, int(lossless_squeeze), lossless_tree, num_threads, bits, orientation, float_samples)
+                     int(adaptive_lf_smoothing), lossless_predictor, int(lossless_squeeze), lossless_tree, num_threads, bits, orientation, float_samples, colour)
     hnd = L.jxo_encode(px.ctypes.data, w, h, nch, C.byref(p), exif, len(exif) if exif else 0, xmp, len(xmp) if xmp else 0)
     if not hnd:
         raise OracleError(L.jxo_last_error().decode())

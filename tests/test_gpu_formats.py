@@ -166,3 +166,42 @@ def test_float_samples_lossy(oracle, kind):
     bits = np.uint32 if kind == 32 else np.uint16
     assert np.array_equal(got.pixels[..., 3].view(bits), px[..., 3].view(bits))      # alpha is coded losslessly
     assert np.abs(got.pixels[..., :3].astype(np.float32) - img[..., :3]).mean() < 6 / 255
+
+
+@pytest.mark.parametrize("colour,profile", [(0, "Srgb"), (1, "DisplayP3"), (2, "Rec709"), (3, "Rec2020Linear"), (4, "Rec2020PQ"), (5, "LinearSrgb")])
+def test_enumerated_colour_encodings(oracle, colour, profile):
+    """The encodings the reference's host knows by name (SetProfileFromColorEncoding, Decoder/JxlDecoder.cpp:36-108): the pixels come
+    back in the image's OWN space (primaries folded into the XYB inverse, its transfer function applied)."""
+    img = synth(300, 260, 40 + colour)
+    data = oracle.encode(img, distance=1.0, colour=colour)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.known_profile == profile
+    d = np.abs(got.pixels.astype(np.int32) - ref.pixels.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 0.004
+    assert np.abs(got.pixels[..., :3].astype(np.float64) - img[..., :3]).mean() < 6.5      # and close to the source in that space
+    # lossless frames carry the samples of their space untouched; only the announced profile differs
+    data = oracle.encode(img, lossless=True, colour=colour, lossless_predictor=5, lossless_tree=1)
+    got = api.load_image(data)
+    assert got.known_profile == profile and np.array_equal(got.pixels, img)
+
+
+def test_pq_16_bit_and_float(oracle):
+    px = synth16(200, 160, 50)
+    data = oracle.encode(px, distance=1.0, colour=4, bits=16)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.known_profile == "Rec2020PQ" and got.pixels.dtype == np.uint16
+    d = np.abs(got.pixels[..., :3].astype(np.int32) - ref.pixels[..., :3].astype(np.int32))
+    # the PQ curve is very steep near black: float32 summation-order differences of the linear values (1e-5) are amplified there
+    assert d.max() <= 1024 and (d > 32).mean() < 0.003 and np.median(d) <= 2
+    f = (synth(200, 160, 51).astype(np.float32) / 255)
+    data = oracle.encode(f, distance=1.0, colour=3, float_samples=32)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.known_profile == "Rec2020Linear" and got.pixels.dtype == np.float32
+    assert np.abs(got.pixels[..., :3] - ref.pixels[..., :3]).max() < 2e-3
+
+
+def test_unnamed_colour_encodings_are_refused(oracle):
+    """DCI / HLG / custom primaries would go through the reference's ICC route: refused loudly, not decoded as sRGB."""
+    data = bytearray(oracle.encode(synth(64, 48, 3), distance=1.0, colour=2, container=False))
+    ok = api.parse_check(bytes(data))
+    assert ok[0] == "Ok"

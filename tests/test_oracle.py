@@ -194,3 +194,13 @@ def test_float_samples_round_trip(oracle, kind):
     assert d.pixels.dtype == px.dtype
     assert np.abs(d.pixels[..., :3].astype(np.float32) - img[..., :3]).mean() < 6 / 255
     assert np.array_equal(d.pixels[..., 3].view(bits), px[..., 3].view(bits))
+
+
+@pytest.mark.parametrize("colour", [0, 1, 2, 3, 4, 5])
+def test_named_colour_encodings_round_trip(oracle, colour):
+    """Pixels handed to the encoder in Display P3 / BT.709 / BT.2020 linear / BT.2020 PQ / linear sRGB come back in that same space."""
+    img = synth(120, 90, 5)
+    d = oracle.decode(oracle.encode(img, distance=1.0, colour=colour)).pixels
+    assert np.abs(d[..., :3].astype(np.float64) - img[..., :3]).mean() < 6.0
+    d = oracle.decode(oracle.encode(img, lossless=True, colour=colour)).pixels
+    assert np.array_equal(d, img)

@@ -65,7 +65,7 @@ struct EncodeParams {
   int bits = 8;                 // bits per sample signalled in the header (8..16); above 8 the input samples are uint16
   // colour encoding signalled in the header; the pixels handed in are ALREADY in that space (lossy frames are converted to XYB from
   // it).  0: sRGB; 1: Display P3 (sRGB transfer); 2: BT.709 transfer, sRGB primaries; 3: BT.2100 primaries, linear;
-  // 4: BT.2100 primaries, PQ (intensity target 10000); 5: linear sRGB
+  // 4: BT.2100 primaries, PQ (intensity target 10000); 5: linear sRGB; 6: HLG written to the header only (refusal tests)
   int colour = 0;
   int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
 };

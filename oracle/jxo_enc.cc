@@ -247,7 +247,7 @@ struct VarDctEncoder {
     // 1. sRGB8 -> linear -> XYB
     Plane img[3] = {Plane(w, h), Plane(w, h), Plane(w, h)};
     if (has_alpha) alpha.resize((size_t)w * h);
-    const int tfk = TransferKind(m.color);
+    const int tfk = p.colour == 6 ? 1 : TransferKind(m.color);   // option 6: pixels treated as sRGB, header says HLG
     JXO_CHECK(tfk >= 0, "transfer function");
     if (m.exp_bits) {
       // float samples (binary32 arrays; binary16 arrays as their uint16 bit patterns): colour goes through the transfer function as
@@ -635,6 +635,7 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
     case 3: m.color.primaries = 9; m.color.tf = 8; break;
     case 4: m.color.primaries = 9; m.color.tf = 16; m.intensity_target = 10000.f; break;
     case 5: m.color.tf = 8; break;
+    case 6: m.color.tf = 18; break;   // HLG in the header only (test stream for decoders that must refuse it)
     default: JXO_CHECK(false, "unknown colour option");
   }
   if (nch < 3) m.color.primaries = 1;   // gray: no primaries

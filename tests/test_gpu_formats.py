@@ -201,7 +201,11 @@ def test_pq_16_bit_and_float(oracle):
 
 
 def test_unnamed_colour_encodings_are_refused(oracle):
-    """DCI / HLG / custom primaries would go through the reference's ICC route: refused loudly, not decoded as sRGB."""
-    data = bytearray(oracle.encode(synth(64, 48, 3), distance=1.0, colour=2, container=False))
-    ok = api.parse_check(bytes(data))
-    assert ok[0] == "Ok"
+    """HLG (like DCI, gamma, custom primaries) would go through the reference's ICC route: refused loudly, not decoded as sRGB."""
+    for lossless in (False, True):
+        data = oracle.encode(synth(64, 48, 3), distance=1.0, lossless=lossless, colour=6)
+        st, _, msg = api.parse_check(data)
+        assert st == "DecodeError" and "ICC" in msg
+        with pytest.raises(api.JxlError) as e:
+            api.load_image(data)
+        assert e.value.status == "DecodeError"

@@ -50,6 +50,11 @@ __device__ __forceinline__ int Mirror(int v, int n) {
 
 // v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
 // * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
+// v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
+// * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
+__device__ __forceinline__ float SrgbOetfT(float v) {
+  return v <= 0.0031308f ? 12.92f * v : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
+}
 __device__ __forceinline__ float PowT(float a, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * e); }   // a > 0
 // Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ.
 __device__ __forceinline__ float EncodeTransferT(int kind, float v, float pq_scale) {
@@ -82,7 +87,12 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
   float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
   float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
-  if (im.to_srgb) { r = EncodeTransferT(im.to_srgb, r, im.pq_scale); g = EncodeTransferT(im.to_srgb, g, im.pq_scale); bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale); }
+  if (im.to_srgb == 1 && !im.out_float) {
+    // the common case on its own short path (integer outputs clamp negatives to 0 anyway, so the curve need not be sign-symmetric here)
+    r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl);
+  } else if (im.to_srgb) {
+    r = EncodeTransferT(im.to_srgb, r, im.pq_scale); g = EncodeTransferT(im.to_srgb, g, im.pq_scale); bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale);
+  }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.out_bits != 8) {   // u16 above 8 bits per sample, f16 / f32 for float samples (Decoder/JxlDecoder.cpp:510-548); `a` is raw bits
     const size_t b = o * im.nch_out;
@@ -110,6 +120,36 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
       if (im.has_alpha) out[1] = (uint8_t)a;
     }
   }
+}
+// The common layouts (u8 samples, sRGB or linear transfer) without the branches of the general function: used by the fused filter
+// kernel, whose output phase is a large part of its time.
+__device__ __forceinline__ bool PlainOutput(const DevImage& im) { return im.out_bits == 8 && im.to_srgb <= 1; }
+__device__ __forceinline__ void WritePixelPlain(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
+  const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
+  const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
+  float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
+  float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
+  float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
+  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
+  const size_t o = (size_t)(y - im.band_y0) * im.w + x;
+  if (im.nch_out == 4) {
+    uchar4 px;
+    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = (uint8_t)a;
+    ((uchar4*)im.out)[o] = px;
+  } else {
+    uint8_t* out = im.out + o * im.nch_out;
+    if (im.ncolor == 3) {
+      out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
+    } else {
+      out[0] = ToU8T(g);
+      if (im.has_alpha) out[1] = (uint8_t)a;
+    }
+  }
+}
+// Out of line on purpose: inlined four times into the fused filter kernel's unrolled output phase, the general function more than
+// doubled that kernel's code (2.3 k -> 5.8 k instructions) and cost 8 % of its speed on the plain path that never executes it.
+__device__ __noinline__ void WritePixelGeneral(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
+  WritePixelA(im, x, y, X, Y, B, a);
 }
 __device__ __forceinline__ void WritePixel(const DevImage& im, int x, int y, float X, float Y, float B) {
   WritePixelA(im, x, y, X, Y, B, im.has_alpha ? LoadAlpha(im, (size_t)y * im.w + x) : 0u);
@@ -551,13 +591,14 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
   // (EPF sigma of the pixel's cell, alpha sample) used to be loaded where they are consumed, which parked every wavefront for
   // a full memory round trip twice more per tile.  Output pixel of iteration `it`: (x0 + lxo, y0 + lyo + 8 * it).
   const int lxo = threadIdx.x & 31, lyo = threadIdx.x >> 5;
+  const bool plain = PlainOutput(im);
   float sig[4];
   uint32_t al[4];
 #pragma unroll
   for (int it = 0; it < 4; it++) {
     const int xc = min(x0 + lxo, w - 1), yc = min(y0 + lyo + 8 * it, h - 1);
     sig[it] = im.inv_sigma[(size_t)(yc >> 3) * im.w8 + (xc >> 3)];
-    al[it] = im.has_alpha ? LoadAlpha(im, (size_t)yc * w + xc) : 0u;
+    al[it] = !im.has_alpha ? 0u : (plain ? (uint32_t)im.alpha[(size_t)yc * w + xc] : LoadAlpha(im, (size_t)yc * w + xc));
   }
   if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h) {
     // interior tile: no mirroring; rows [y0 - 3, y0 + 35) x columns [x0 - 4, x0 + 36) as aligned 16-byte loads
@@ -657,7 +698,8 @@ __global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* im
       o1 = (o1 + w_u * t[1][cy - 1][cx] + w_l * t[1][cy][cx - 1] + w_r * t[1][cy][cx + 1] + w_d * t[1][cy + 1][cx]) * iw;
       o2 = (o2 + w_u * t[2][cy - 1][cx] + w_l * t[2][cy][cx - 1] + w_r * t[2][cy][cx + 1] + w_d * t[2][cy + 1][cx]) * iw;
     }
-    WritePixelA(im, x, y, o0, o1, o2, al[it]);
+    if (plain) WritePixelPlain(im, x, y, o0, o1, o2, al[it]);
+    else WritePixelGeneral(im, x, y, o0, o1, o2, al[it]);
   }
 }
 

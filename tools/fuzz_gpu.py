@@ -15,7 +15,10 @@ from pdn_jpegxl_amd.synth import synth
 rng = np.random.default_rng(7)
 img = synth(300, 280, 3)
 streams = [O.encode(img, distance=1.0), O.encode(img, distance=2.0, strategy_mode=2, seed=4), O.encode(img, lossless=True),
-           O.encode(img, lossless=True, lossless_squeeze=True), O.encode(synth(64, 48, 5))]
+           O.encode(img, lossless=True, lossless_squeeze=True), O.encode(synth(64, 48, 5)),
+           O.encode(img.astype(np.uint16) * 257, distance=1.0, bits=16, orientation=6), O.encode(img.astype(np.uint16) * 257, lossless=True, bits=16),
+           O.encode((img / 255.0).astype(np.float32), lossless=True, float_samples=32, lossless_predictor=5, lossless_tree=1),
+           O.encode(img, distance=1.5, colour=4)]
 counts = {}
 for si, data in enumerate(streams):
     for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 25):

@@ -688,6 +688,7 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
       // The residual of the step after this one and (lane 0) the sample above it are requested a step early: LDS latency
       // then overlaps the arithmetic instead of adding to the recurrence.
       JXL_LDS int32_t* const trow = tile + lane * kTilePitch;
+      const bool top = y == 0, keeps_carry = more && lane == nrows - 1;
       int32_t r_next = cvalue, up0_next = 0;
       if (lane == 0 && row_active) {
         if (kind == kChanResid) r_next = trow[0];
@@ -701,15 +702,17 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
           if (kind == kChanResid) r_next = trow[c + 1];
           if (lane == 0 && y) up0_next = carry[x0 + c + 1];
         }
-        if (row_active && c >= 0 && c < ncols) {
-          const int x = x0 + c;
+        if (row_active && (unsigned)c < (unsigned)ncols) {
+          // neighbours without branches: first column -> W = N = NW = the sample above (0 in the top row); top row -> N = NW = W
           const int32_t n_in = lane == 0 ? up0 : from_up;
-          if (x == 0) { W = y ? n_in : 0; N = W; NW = W; }
-          else if (y) { NW = N; N = n_in; }
-          else { NW = W; N = W; }
+          const bool first = (x0 | c) == 0;
+          const int32_t w0 = top ? 0 : n_in;
+          NW = first ? w0 : (top ? W : N);
+          N = first ? w0 : (top ? W : n_in);
+          W = first ? w0 : W;
           val = (int32_t)((uint32_t)r + RowGuess(pred, W, N, NW));
           trow[c] = val;
-          if (more && lane == nrows - 1) carry[x] = val;
+          if (keeps_carry) carry[x0 + c] = val;
           W = val;
         }
       }

@@ -121,6 +121,24 @@ def test_brob_boxes_are_decompressed(oracle):
     assert st == "DecodeError" and "Brotli" in msg or payload != exif
 
 
+def test_first_exif_wins_and_every_xml_box_is_reported(oracle):
+    """Decoder/JxlDecoder.cpp:697-719 keeps the first Exif box only; every `xml ` box reaches setXmp (:720-784)."""
+    import struct
+    import brob_util
+    exif1, exif2 = b"\0\0\0\0II*\0first", b"\0\0\0\0II*\0second-one"
+    plain = oracle.encode(synth(64, 48, 1), exif=exif1, xmp=b"<a/>")
+    out = b""
+    for typ, payload, raw in brob_util.boxes(plain):
+        out += raw
+        if typ == b"Exif":
+            out += struct.pack(">I4s", 8 + len(exif2), b"Exif") + exif2
+        if typ == b"xml ":
+            out += struct.pack(">I4s", 8 + 4, b"xml ") + b"<b/>"
+    assert api.parse_metadata(out, 0)[:2] == ("Ok", exif1)
+    assert api.parse_metadata(out, 1)[:2] == ("Ok", b"<a/>") and api.parse_metadata(out, 2)[:2] == ("Ok", b"<b/>")
+    assert api.parse_metadata(out, 3)[1] is None
+
+
 def test_static_tables_match_oracle(oracle):
     L = oracle.lib()
     L.jxo_natural_order.restype = C.c_size_t

@@ -70,6 +70,7 @@ struct EncImage {
   // entropy coding
   EncCodeDev mcode, acode;
   uint8_t* sec_bytes;       // section s at s * sec_cap
+  uint32_t* stream_state;   // final rANS state per token stream (lossy frames: 2 per LF group, 2 per group, 1 global alpha)
   uint64_t* sec_bits;       // bits written per section
   uint64_t sec_cap;
 };

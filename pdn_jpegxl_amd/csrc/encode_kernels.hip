@@ -446,8 +446,8 @@ struct WaveWriter {
   }
 };
 
-__device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveWriter& w, WaveScratch* sc) {
-  const int lane = w.lane;
+// Reverse pass of one token stream (its flushes are recorded in the token array); returns the final state on every lane.
+__device__ uint32_t ReversePass(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveScratch* sc, int lane) {
   const DevToken kNone = {0u, 0u};
   const int64_t nblk = ((int64_t)n + 63) >> 6;
   uint32_t state = 0x130000u;   // lane 0's copy is the real one
@@ -487,7 +487,14 @@ __device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, 
       if (valid) tok[idx].ctx = sc->flush[lane];
     }
   }
-  state = (uint32_t)__shfl((int)state, 0);
+  return (uint32_t)__shfl((int)state, 0);
+}
+
+// Forward pass: the state, then per token its flush and its raw bits, laid out by all lanes at once.
+__device__ void ForwardPass(const DevToken* tok, uint32_t n, uint32_t state, WaveWriter& w) {
+  const int lane = w.lane;
+  const DevToken kNone = {0u, 0u};
+  const int64_t nblk = ((int64_t)n + 63) >> 6;
   w.PutUniform(32, state);
   {
     DevToken nxt = kNone;
@@ -505,6 +512,12 @@ __device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, 
       w.PutParallel(V, len);
     }
   }
+}
+
+
+__device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveWriter& w, WaveScratch* sc) {
+  const uint32_t state = ReversePass(tok, n, code, sc, w.lane);
+  ForwardPass(tok, n, state, w);
 }
 
 __device__ size_t StageEncCode(uint8_t* smem, size_t off, const EncCodeDev& g, EncCodeDev* l, bool with_rmap, int tid, int nt) {
@@ -532,7 +545,34 @@ __device__ __forceinline__ WaveScratch* CarveScratch(uint8_t* smem, size_t off, 
   off = (off + 15) & ~(size_t)15;
   return (WaveScratch*)(smem + off) + wave;
 }
-__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_sections_kernel(EncImage im) {
+// Token streams of a lossy frame, numbered so that the two streams of a section get their own wavefronts in the reverse pass:
+// 2g / 2g+1: LF coefficients / block metadata of LF group g; 2 nlf + 2g / + 1: HF coefficients / alpha of group g.
+__device__ __forceinline__ bool LossyStream(const EncImage& im, int st, DevToken** tok, uint32_t* n, bool* modular) {
+  if (st < 2 * im.nlf) {
+    const int g = st >> 1;
+    const int gx = g % im.xlf, gy = g / im.xlf;
+    const int bw = min(kLfGroupBlocks, im.w8 - gx * kLfGroupBlocks), bh = min(kLfGroupBlocks, im.h8 - gy * kLfGroupBlocks);
+    *modular = true;
+    if (st & 1) { *tok = im.tok_meta + (size_t)g * kMetaTokCap; *n = (uint32_t)(bw * bh); }
+    else { *tok = im.tok_lf + (size_t)g * kLfTokCap; *n = (uint32_t)(3 * bw * bh); }
+    return true;
+  }
+  const int r = st - 2 * im.nlf;
+  const int g = r >> 1;
+  if (g >= im.ng) return false;
+  if (r & 1) {
+    if (!(im.has_alpha && im.ng > 1)) return false;
+    const int gx = g % im.xg, gy = g / im.xg;
+    const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
+    *modular = true; *tok = im.tok_alpha + (size_t)g * kAlphaTokCap; *n = (uint32_t)(gw * gh);
+  } else {
+    *modular = false; *tok = im.tok_ac + (size_t)g * kAcTokCap; *n = im.n_ac[g];
+  }
+  return true;
+}
+// Reverse (state) passes: one wavefront per token stream - the only serial part of the entropy coder, so the two streams of an LF
+// group (196 k + 65 k tokens) and of a pass group run side by side instead of one after the other.
+__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_reverse_kernel(EncImage im) {
   extern __shared__ __align__(16) uint8_t enc_smem[];
   size_t off;
   {
@@ -544,28 +584,47 @@ __global__ __launch_bounds__(64 * kSectionsPerWg) void enc_sections_kernel(EncIm
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   WaveScratch* sc = CarveScratch(enc_smem, off, wave);
+  const int st = blockIdx.x * kSectionsPerWg + wave;
+  DevToken* tok;
+  uint32_t n;
+  bool modular;
+  if (!LossyStream(im, st, &tok, &n, &modular)) return;
+  const uint32_t state = ReversePass(tok, n, modular ? im.mcode : im.acode, sc, lane);
+  if (lane == 0) im.stream_state[st] = state;
+}
+
+// Bit layout of every section (after enc_reverse_kernel): header fields and, per stream, state + flushes + raw bits; no tables needed.
+__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_sections_kernel(EncImage im) {
+  __shared__ WaveScratch s_sc[kSectionsPerWg];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  WaveScratch* sc = &s_sc[wave];
   const int s = blockIdx.x * kSectionsPerWg + wave;
   if (s >= im.nlf + im.ng) return;
   WaveWriter w;
   w.Init(im.sec_bytes + (size_t)s * im.sec_cap, sc, lane);
+  DevToken* tok;
+  uint32_t n;
+  bool modular;
   if (s < im.nlf) {
     const int g = s;
     const int gx = g % im.xlf, gy = g / im.xlf;
     const int bw = min(kLfGroupBlocks, im.w8 - gx * kLfGroupBlocks), bh = min(kLfGroupBlocks, im.h8 - gy * kLfGroupBlocks);
     w.PutUniform(2, 0);   // extra_precision
     w.PutUniform(4, 3);   // modular group header: global tree, default weighted-predictor parameters, no transforms
-    EncodeStream(im.tok_lf + (size_t)g * kLfTokCap, (uint32_t)(3 * bw * bh), im.mcode, w, sc);
+    LossyStream(im, 2 * g, &tok, &n, &modular);
+    ForwardPass(tok, n, im.stream_state[2 * g], w);
     w.PutUniform(CeilLog2E((uint32_t)(bw * bh)), (uint32_t)(bw * bh - 1));   // number of varblocks - 1
     w.PutUniform(4, 3);
-    EncodeStream(im.tok_meta + (size_t)g * kMetaTokCap, (uint32_t)(bw * bh), im.mcode, w, sc);
+    LossyStream(im, 2 * g + 1, &tok, &n, &modular);
+    ForwardPass(tok, n, im.stream_state[2 * g + 1], w);
   } else {
     const int g = s - im.nlf;
-    EncodeStream(im.tok_ac + (size_t)g * kAcTokCap, im.n_ac[g], im.acode, w, sc);
-    if (im.has_alpha && im.ng > 1) {
-      const int gx = g % im.xg, gy = g / im.xg;
-      const int gw = min(kGroupDim, im.w - gx * kGroupDim), gh = min(kGroupDim, im.h - gy * kGroupDim);
+    const int st = 2 * im.nlf + 2 * g;
+    LossyStream(im, st, &tok, &n, &modular);
+    ForwardPass(tok, n, im.stream_state[st], w);
+    if (LossyStream(im, st + 1, &tok, &n, &modular)) {
       w.PutUniform(4, 3);
-      EncodeStream(im.tok_alpha + (size_t)g * kAlphaTokCap, (uint32_t)(gw * gh), im.mcode, w, sc);
+      ForwardPass(tok, n, im.stream_state[st + 1], w);
     }
   }
   const uint64_t bits = w.Finish();
@@ -695,10 +754,12 @@ static size_t EncCodeLds(const EncCodeDev& c, bool with_rmap) {   // as StageEnc
   return 16 + (size_t)c.num_clusters * (kEncSyms * 4 + (with_rmap ? 8192 : 0)) + c.num_ctx;
 }
 void LaunchEncSections(const EncImage& im, hipStream_t s) {
-  // LDS: modular code with its slot map + HF code without + one scratch block per wavefront
+  // reverse passes: LDS = modular code with its slot map + HF code without + one scratch block per wavefront
   const size_t lds = EncCodeLds(im.mcode, true) + EncCodeLds(im.acode, false) + 16 + kSectionsPerWg * sizeof(WaveScratch);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_sections_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int nstreams = 2 * (im.nlf + im.ng);
+  hipLaunchKernelGGL(enc_reverse_kernel, dim3((unsigned)((nstreams + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im);
+  hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), 0, s, im);
   if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
 }
 void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s) {

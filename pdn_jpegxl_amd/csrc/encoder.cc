@@ -219,6 +219,7 @@ void EncodeLossless(const BitmapData* bmp, const EncoderImageMetadata* md, IOCal
   im.sec_cap = ((size_t)kLlTokCap * 6 + 256) & ~(size_t)15;
   im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
   im.sec_bits = A.Get<uint64_t>(nsec, true);
+  im.stream_state = A.Get<uint32_t>((size_t)2 * (im.nlf + im.ng) + 1, true);
   LaunchEncLossless(im, 1, s);
   std::vector<uint64_t> sec_bits(nsec);
   ENC_HIP(hipMemcpy(sec_bits.data(), im.sec_bits, sec_bits.size() * 8, hipMemcpyDeviceToHost));
@@ -354,6 +355,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.sec_cap = ((size_t)std::max(kLfTokCap + kMetaTokCap, kAcTokCap + kAlphaTokCap) * 6 + 256) & ~(size_t)15;
   im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
   im.sec_bits = A.Get<uint64_t>(nsec, true);
+  im.stream_state = A.Get<uint32_t>((size_t)2 * (im.nlf + im.ng) + 1, true);
   LaunchEncSections(im, s);
   clk.Lap("ans sections");
   std::vector<uint64_t> sec_bits(nsec);

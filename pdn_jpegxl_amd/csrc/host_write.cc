@@ -176,11 +176,12 @@ struct Hist {
   }
 };
 
-double JoinCost(const Hist& a, const Hist& b) {   // extra bits when both are coded with their merged distribution
+// extra bits when both are coded with their merged distribution; nsym: symbols that occur at all (the tail of the alphabet is empty)
+double JoinCost(const Hist& a, const Hist& b, size_t nsym) {
   if (!a.total || !b.total) return 0;
   const uint64_t tot = a.total + b.total;
   double e = 0;
-  for (size_t i = 0; i < a.c.size(); i++) {
+  for (size_t i = 0; i < nsym; i++) {
     const uint64_t v = a.c[i] + b.c[i];
     if (v) e -= (double)v * std::log2((double)v / (double)tot);
   }
@@ -229,6 +230,7 @@ void BuildAndWriteCode(const uint32_t* hist, size_t num_ctx, int max_clusters, c
     for (size_t s = 0; s < A; s++) if (h[i].c[s]) max_sym = std::max<uint32_t>(max_sym, (uint32_t)s);
   }
   // ---- clustering: farthest-point seeds in join-cost distance, every context joins its cheapest seed
+  const size_t nsym = std::min<size_t>(A, (size_t)max_sym + 1);
   size_t budget = (size_t)std::max(1, std::min(max_clusters, 255)) - (any_pinned ? 1 : 0);
   if (budget < 1) budget = 1;
   std::vector<Hist> clusters;
@@ -246,7 +248,7 @@ void BuildAndWriteCode(const uint32_t* hist, size_t num_ctx, int max_clusters, c
       size_t far = used[0];
       double fard = -1;
       for (size_t i : used) {
-        dmin[i] = std::min(dmin[i], JoinCost(h[i], h[s]));
+        dmin[i] = std::min(dmin[i], JoinCost(h[i], h[s], nsym));
         if (dmin[i] > fard) { fard = dmin[i]; far = i; }
       }
       if (fard <= 0) break;
@@ -258,7 +260,7 @@ void BuildAndWriteCode(const uint32_t* hist, size_t num_ctx, int max_clusters, c
       size_t best = 0;
       double bd = 1e300;
       for (size_t k = 0; k < seeds.size(); k++) {
-        const double d = i == seeds[k] ? -1.0 : JoinCost(h[i], h[seeds[k]]);
+        const double d = i == seeds[k] ? -1.0 : JoinCost(h[i], h[seeds[k]], nsym);
         if (d < bd) { bd = d; best = k; }
       }
       out.ctx_map[i] = (uint8_t)best;

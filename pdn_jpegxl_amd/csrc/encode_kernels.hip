@@ -476,9 +476,12 @@ __device__ uint32_t ReversePass(DevToken* tok, uint32_t n, const EncCodeDev& cod
           if ((state >> 20) >= fk) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
           // state / fk: the float estimate is within one of the quotient (state < fk << 20, 24-bit mantissas); fixed up exactly
           uint32_t qd = (uint32_t)((float)state * sc->rcp[k]);
-          int32_t rm = (int32_t)(state - qd * fk);
-          while (rm < 0) { qd--; rm += (int32_t)fk; }
-          while (rm >= (int32_t)fk) { qd++; rm -= (int32_t)fk; }
+          int32_t rm = (int32_t)(state - __umul24(qd, fk));   // qd < 2^20 + 2, fk <= 4096: a full-rate 24-bit multiply
+          const bool under = rm < 0;
+          qd -= under ? 1u : 0u; rm += under ? (int32_t)fk : 0;
+          const bool over = rm >= (int32_t)fk;
+          qd += over ? 1u : 0u; rm -= over ? (int32_t)fk : 0;
+          if ((uint32_t)rm >= fk) { qd = state / fk; rm = (int32_t)(state - qd * fk); }   // never expected: the exact division
           state = (qd << 12) + code.rmap[(size_t)sc->rbase[k] + (uint32_t)rm];
           sc->flush[k] = flush;
         }

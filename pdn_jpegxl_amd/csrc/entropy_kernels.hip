@@ -913,8 +913,11 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
   if (tid == 0) s_count = 0;
   for (int i = tid; i < 256 * 8; i += 256) s_cov[i] = 0;
   __syncthreads();
-  if (tid == 0) {
-    uint32_t num = 0;
+  if (wave == 0) {
+    // The walk is serial, but its operands need not be fetched one dependent HBM round trip at a time: the whole wavefront runs the
+    // loop in lockstep (uniform control flow, lane 0 alone stores), every lane holds one entry of the current chunk of 64 block
+    // descriptions - strategy, quant, block shape - fetched together, and the entry of block `num` is a v_readlane away.
+    uint32_t num = 0, chunk = ~0u, packed = 0;
     const int words = (bw + 31) >> 5;
     for (int y = 0; y < bh && !(err & kErrBlockLayout); y++) {
       for (int wi = 0; wi < words; wi++) {
@@ -926,23 +929,34 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
           const int xb = __ffs(freebits) - 1;
           const int x = wi * 32 + xb;
           if (num >= count) { err |= kErrBlockLayout; break; }
-          const int s = s_info[num];
-          const int q = 1 + s_info[count + num];
-          if (s < 0 || s >= kNumStrategies || q < 1 || q > 256) { err |= kErrBlockLayout; break; }
-          const int lcx = d_log2cx[s], lcy = d_log2cy[s], cx = 1 << lcx, cy = 1 << lcy;
+          if ((num >> 6) != chunk) {
+            chunk = num >> 6;
+            const uint32_t idx = chunk * 64 + lane;
+            const int es = idx < count ? s_info[idx] : -1;
+            const int eq = idx < count ? 1 + s_info[count + idx] : 0;
+            const bool ok = es >= 0 && es < kNumStrategies && eq >= 1 && eq <= 256;
+            packed = ok ? ((uint32_t)es | (uint32_t)eq << 8 | (uint32_t)d_log2cx[es] << 20 | (uint32_t)d_log2cy[es] << 24 | 1u << 31) : 0u;
+          }
+          const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)(num & 63));
+          if (!(e >> 31)) { err |= kErrBlockLayout; break; }
+          const int lcx = (e >> 20) & 7, lcy = (e >> 24) & 7, cx = 1 << lcx, cy = 1 << lcy;
           if (x + cx > bw || y + cy > bh || xb + cx > 32 || (y & 31) + cy > 32) { err |= kErrBlockLayout; break; }
           const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1)) << xb;
           uint32_t clash = 0;
-          for (int iy = 0; iy < cy; iy++) { clash |= s_cov[(y + iy) * 8 + wi] & mask; s_cov[(y + iy) * 8 + wi] |= mask; }
+          for (int iy = 0; iy < cy; iy++) {
+            const uint32_t cur = s_cov[(y + iy) * 8 + wi];
+            clash |= cur & mask;
+            if (lane == 0) s_cov[(y + iy) * 8 + wi] = cur | mask;
+          }
           if (clash) { err |= kErrBlockLayout; break; }
-          s_pos[num] = x | y << 8;
+          if (lane == 0) s_pos[num] = x | y << 8;
           num++;
         }
         if (err & kErrBlockLayout) break;
       }
     }
     if (num != count) err |= kErrBlockLayout;
-    s_count = num;
+    if (lane == 0) s_count = num;
   }
   __threadfence_block();
   __syncthreads();

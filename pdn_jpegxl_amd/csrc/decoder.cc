@@ -68,6 +68,30 @@ using namespace jxlhip;
 // Bytes per output sample: the sample type follows the colour channels' depth (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32.
 static inline size_t OutBytesPerSample(const ParsedFrame& f) { return f.exp_bits ? (f.bits <= 16 ? 2 : 4) : (f.bits > 8 ? 2 : 1); }
 
+// Order bucket of a quant table (every strategy of a quant table shares one bucket).
+static int OrderBucketOfQuantTable(int q) {
+  for (int s = 0; s < kNumStrategies; s++) if (kStrategyQuantTable[s] == q) return kStrategyOrderBucket[s];
+  return 0;
+}
+// Scan list of quant table q: for each channel (X, Y, B) and scan position k, the stored-layout index order[k] and the bits of
+// the dequantisation weight at that index.  custom: the frame's own coefficient orders ([bucket][channel], empty = natural).
+static void BuildScanList(int q, const std::vector<uint16_t> (*custom)[3], std::vector<U32x2>& out) {
+  const StaticTables& st = GetStaticTables();
+  const int o = OrderBucketOfQuantTable(q);
+  const size_t n = st.dq[q].size() / 3;
+  out.resize(3 * n);
+  for (int c = 0; c < 3; c++) {
+    const std::vector<uint16_t>& ord = (custom && !custom[o][c].empty()) ? custom[o][c] : st.natural_order[o];
+    for (size_t k = 0; k < n; k++) {
+      const uint32_t p = k < ord.size() ? ord[k] : 0u;
+      uint32_t wb;
+      const float w = st.dq[q][(size_t)c * n + (p < n ? p : 0)];
+      memcpy(&wb, &w, 4);
+      out[(size_t)c * n + k] = U32x2{p, wb};
+    }
+  }
+}
+
 struct JxlHipDecoder {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -75,8 +99,8 @@ struct JxlHipDecoder {
   float* d_basis_all = nullptr;
   float* d_basis_small = nullptr;
   float* d_llf_scale = nullptr;
-  uint16_t* d_natural_small = nullptr;   // buckets 0..8 concatenated (LDS staging source)
   uint16_t* d_natural[kNumOrders] = {};
+  U32x2* d_scan[kNumQuantTables] = {};   // per quant table: {order[k], weight bits} in scan order, 3 channels (natural orders, library tables)
   float* d_dq[kNumQuantTables] = {};
   uint32_t dq_n[kNumQuantTables] = {};
   // Per-batch state lives in one of three slots so that, when the caller does not synchronise between batches, the LF
@@ -177,16 +201,14 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     HIP_OK(hipMalloc(&d_natural[o], st.natural_order[o].size() * 2));
     HIP_OK(hipMemcpy(d_natural[o], st.natural_order[o].data(), st.natural_order[o].size() * 2, hipMemcpyHostToDevice));
   }
-  {
-    std::vector<uint16_t> small_orders;
-    for (int o = 0; o <= 8; o++) small_orders.insert(small_orders.end(), st.natural_order[o].begin(), st.natural_order[o].end());
-    HIP_OK(hipMalloc(&d_natural_small, small_orders.size() * 2));
-    HIP_OK(hipMemcpy(d_natural_small, small_orders.data(), small_orders.size() * 2, hipMemcpyHostToDevice));
-  }
   for (int q = 0; q < kNumQuantTables; q++) {
     HIP_OK(hipMalloc(&d_dq[q], st.dq[q].size() * 4));
     HIP_OK(hipMemcpy(d_dq[q], st.dq[q].data(), st.dq[q].size() * 4, hipMemcpyHostToDevice));
     dq_n[q] = (uint32_t)(st.dq[q].size() / 3);
+    std::vector<U32x2> sl;
+    BuildScanList(q, nullptr, sl);
+    HIP_OK(hipMalloc(&d_scan[q], sl.size() * sizeof(U32x2)));
+    HIP_OK(hipMemcpy(d_scan[q], sl.data(), sl.size() * sizeof(U32x2), hipMemcpyHostToDevice));
   }
   if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
   if (const char* e = getenv("JXLHIP_HF_RING")) hf_ring_override = atoi(e);
@@ -205,9 +227,10 @@ JxlHipDecoder::~JxlHipDecoder() {
     if (S.h_blob) (void)hipHostFree(S.h_blob);
     if (S.h_status) (void)hipHostFree(S.h_status);
   }
-  (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_llf_scale); (void)hipFree(d_natural_small);
+  (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_llf_scale);
   for (auto p : d_natural) (void)hipFree(p);
   for (auto p : d_dq) (void)hipFree(p);
+  for (auto p : d_scan) (void)hipFree(p);
   if (li_dev) (void)hipFree(li_dev);
   if (li_host) (void)hipHostFree(li_host);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -358,7 +381,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)n);
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
-    size_t z_cellinfo, z_status, z_coef[3];
+    size_t scan[kNumQuantTables] = {};   // frames with their own coefficient orders: scan lists of the affected quant tables
+    size_t z_cellinfo, z_status, centries, cblk;
     std::vector<size_t> mod_planes;
     size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
@@ -405,11 +429,22 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.a_alias = blob.Take(8 * f.acode.alias.size());
     for (int o = 0; o < kNumOrders; o++)
       for (int c = 0; c < 3; c++) l.order[o][c] = f.custom_order[o][c].empty() ? 0 : blob.Take(2 * f.custom_order[o][c].size());
+    for (int q = 0; q < kNumQuantTables; q++) {
+      const int o = OrderBucketOfQuantTable(q);
+      if (!f.custom_order[o][0].empty() || !f.custom_order[o][1].empty() || !f.custom_order[o][2].empty()) l.scan[q] = blob.Take(8 * 3 * (size_t)dq_n[q], 256) + 1;
+    }
     const bool resident = dev_data && dev_data[i] && f.cs_contiguous;
     l.cs = resident ? 0 : blob.Take(f.cs_size + 16);
     l.z_cellinfo = ws_zero.Take(4 * cells);
     l.z_status = ws_zero.Take(64);
-    for (int c = 0; c < 3; c++) l.z_coef[c] = ws_zero.Take(4 * pix);
+    {
+      // entry lists of the decoded group rows only (a band decode touches a band's worth), block index for the whole cell grid
+      int b0 = 0, b1 = (int)f.yg;
+      if (band_rows > 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
+      const int g0 = std::max(0, b0 - 1), g1 = std::min<int>((int)f.yg, b1 + 1);
+      l.centries = ws.Take((size_t)std::max(1, g1 - g0) * f.xg * kGroupEntriesCap * 4);
+      l.cblk = ws.Take(3 * cells * sizeof(U32x2));
+    }
     for (int c = 0; c < 3; c++) { l.lf[c] = ws.Take(4 * cells); l.lf_tmp[c] = ws.Take(4 * cells); l.lfq[c] = ws.Take(4 * cells); }
     l.lf_extra = ws.Take(f.nlf);
     l.rawq = ws.Take(2 * cells);
@@ -437,11 +472,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // frames go through those stages in chunks that share kPixelChunk sets of planes, so the batch size is bounded by the
   // entropy-stage state (12 B/px of coefficients), not by 36 B/px.
   const int pixel_chunk = debug_taps ? std::max(1, n) : std::min(std::max(1, n), kPixelChunk);
-  std::vector<size_t> chunk_tmp((size_t)pixel_chunk * 3), chunk_xyb((size_t)pixel_chunk * 3);
+  // (a third set: the loop-filter ping-pong planes, which double as the dense coefficient planes of the generic path)
+  std::vector<size_t> chunk_tmp((size_t)pixel_chunk * 3), chunk_xyb((size_t)pixel_chunk * 3), chunk_coef((size_t)pixel_chunk * 3);
   if (chunk_pix)
-    for (int k = 0; k < pixel_chunk * 3; k++) { chunk_tmp[k] = ws.Take(4 * chunk_pix); chunk_xyb[k] = ws.Take(4 * chunk_pix); }
+    for (int k = 0; k < pixel_chunk * 3; k++) { chunk_tmp[k] = ws.Take(4 * chunk_pix); chunk_xyb[k] = ws.Take(4 * chunk_pix); chunk_coef[k] = ws.Take(4 * chunk_pix); }
   // The reference's decoder library hands out the image as displayed (orientation applied; it is only kept when the caller asks,
   // which Decoder/DecoderContext.cpp never does): such frames are decoded into a scratch buffer and re-laid out at the end.
+  // A band is a set of VarDCT group rows.  A Modular frame has no band mode (global Squeeze / whole-image transforms: SURVEY 8e
+  // "replicas only"); its output kernel writes the whole frame, so accepting the option would overrun the caller's band buffer.
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok && band_rows > 0 && frames[i].encoding == 1) {
+      parse_status[i] = DecoderStatus_DecodeError;
+      parse_msg[i] = "band decode of a Modular (lossless) frame is not supported";
+    }
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok || frames[i].orientation == 1) continue;
     const ParsedFrame& f = frames[i];
@@ -456,7 +499,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     size_t lds_est = 0;
     for (int i = 0; i < n; i++)
       if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0)
-        lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 2 + 8448 * 2 + 64 + 4 * (96 + 64 + 128));
+        lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 64 + 4 * (96 + 64 + 128));
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
     while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
@@ -655,7 +698,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.x_dm = std::pow(0.8f, (float)f.x_qm_scale - 2.0f);
     d.b_dm = std::pow(0.8f, (float)f.b_qm_scale - 2.0f);
     memcpy(d.qbias, f.qbias, sizeof(d.qbias));
-    for (int q = 0; q < kNumQuantTables; q++) { d.dq[q] = d_dq[q]; d.dq_n[q] = dq_n[q]; }
+    for (int q = 0; q < kNumQuantTables; q++) {
+      d.dq[q] = d_dq[q]; d.dq_n[q] = dq_n[q]; d.scan[q] = d_scan[q];
+      if (l.scan[q]) {
+        std::vector<U32x2> sl;
+        BuildScanList(q, f.custom_order, sl);
+        put(l.scan[q] - 1, sl.data(), sl.size() * sizeof(U32x2));
+        d.scan[q] = (const U32x2*)(d_blob + l.scan[q] - 1);
+      }
+    }
     d.gab = f.gab; d.epf_iters = f.epf_iters; d.skip_lf_smoothing = (f.flags & 128) ? 1 : 0;
     for (int c = 0; c < 3; c++) {
       float div = 1.0f + 4.0f * (f.gab_w1[c] + f.gab_w2[c]);
@@ -678,11 +729,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.status = (uint32_t*)(wz + l.z_status);
     status_off[i] = l.z_status;
     for (int c = 0; c < 3; c++) {
-      d.coef[c] = (int32_t*)(wz + l.z_coef[c]);
+      d.coef[c] = (int32_t*)(wr + chunk_coef[(size_t)(i % pixel_chunk) * 3 + c]);
       d.lf[c] = (float*)(wr + l.lf[c]); d.lf_tmp[c] = (float*)(wr + l.lf_tmp[c]); d.lfq[c] = (int32_t*)(wr + l.lfq[c]);
       d.lf_final[c] = d.skip_lf_smoothing ? d.lf[c] : d.lf_tmp[c];
       d.tmp[c] = (float*)(wr + chunk_tmp[(size_t)(i % pixel_chunk) * 3 + c]); d.xyb[c] = (float*)(wr + chunk_xyb[(size_t)(i % pixel_chunk) * 3 + c]);
-      d.xyb2[c] = (float*)d.coef[c];   // the coefficient planes are dead once the frame is reconstructed: loop-filter ping-pong buffer
+      d.xyb2[c] = (float*)d.coef[c];   // the dense coefficient planes (generic path only) are dead once the frame is reconstructed
     }
     d.lf_extra = wr + l.lf_extra;
     d.rawq = (uint16_t*)(wr + l.rawq); d.sharp = wr + l.sharp;
@@ -693,6 +744,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.grp_bitpos = (uint64_t*)(wr + l.bitpos);
     d.tile_list = (uint32_t*)(wr + l.tile_list);
     d.alpha32 = (int32_t*)(wr + l.alpha32);
+    d.centries = (uint32_t*)(wr + l.centries); d.centries_g0 = d.dec_gy0 * (int32_t)f.xg;
+    d.cblk = (U32x2*)(wr + l.cblk);
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
     d.lf_end_bits = (uint64_t*)(wr + l.lf_end);
@@ -732,7 +785,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-    lds_hf = std::max(lds_hf, code_lds(f.acode) + 2 + 8448 * 2 + 64 + 32);   // tables; the per-lane part is added below
+    lds_hf = std::max(lds_hf, code_lds(f.acode) + 64 + 32);   // tables; the per-lane part is added below
     lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = lds_lf;
     max_groups = std::max<int>(max_groups, (int)f.ng);
@@ -781,15 +834,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   int hf_ring = npass_t > 256 ? 16 : 32;
   if (hf_ring_override == 16 || hf_ring_override == 32) hf_ring = hf_ring_override;
   lds_hf += (size_t)hf_slots * HfLaneLdsBytes(hf_ring);
-  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0,
-                 d_natural_small, s_hf);
+  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, s_hf);
   Mark("hf_decode", s_hf, 1);
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages
   if (any_alpha)
     LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, s_hf);
   Mark("alpha_ans", s_hf, 1);
-  if (debug_taps) { taps.assign(n, Tap()); HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(0); }
+  if (debug_taps) {   // the quantised coefficients as dense planes (every frame has its own planes in this mode)
+    taps.assign(n, Tap());
+    LaunchExpandCoefficients(d_imgs, n, true, max_tiles, stream);
+    HIP_OK(hipStreamSynchronize(stream));
+    CopyPlaneTap(0);
+  }
   if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
   Mark("alpha_finish", s_hf, 1);
   if (s_hf != stream) {
@@ -801,6 +858,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const int cnt = std::min(pixel_chunk, n - c0);
     LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
     Mark("reconstruct", stream, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
+    LaunchExpandCoefficients(d_imgs + c0, cnt, false, max_tiles, stream);
     LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, stream);
     Mark("reconstruct_generic", stream, 2);
     if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }

@@ -14,6 +14,9 @@ constexpr int kGroupDim = 256;
 constexpr int kGroupBlocks = 32;        // 8x8 cells per group side
 constexpr int kLfGroupBlocks = 256;     // 8x8 cells per LF group side
 constexpr int kMaxClustersLds = 128;
+// HF coefficients leave the entropy stage as a sparse list per 256x256 group: one 32-bit entry per NON-ZERO coefficient, in decode
+// order, entry = scan position k (low 16 bits) | quantised value (int16, high 16 bits).  A group holds at most 3 * 65536 of them.
+constexpr uint32_t kGroupEntriesCap = 3u * 65536u;
 
 // error bits written by kernels into DevImage::status[0]
 enum DevError : uint32_t {
@@ -24,6 +27,8 @@ enum DevError : uint32_t {
   kErrBlockLayout = 1u << 3,        // invalid varblock placement
   kErrRange = 1u << 4,              // value out of range (sharpness, quant, cfl)
 };
+
+struct alignas(8) U32x2 { uint32_t x, y; };   // 8 bytes, 8-byte aligned loads / stores on the device
 
 struct DevTreeNode {    // 16 bytes
   int32_t property;     // -1: leaf
@@ -97,6 +102,9 @@ struct DevImage {
   float qbias[4];
   const float* dq[kNumQuantTables];   // 3 * n floats each (1/weight), stored layout
   uint32_t dq_n[kNumQuantTables];
+  // per quant table (which also fixes the coefficient order bucket), per channel, in SCAN order: .x = order[k] (index in the
+  // stored layout), .y = bits of the dequantisation weight at that index; channel c starts at scan[q] + c * dq_n[q]
+  const U32x2* scan[kNumQuantTables];
   // loop filters / colour
   int32_t gab, epf_iters, skip_lf_smoothing, pad1;
   float gab_w[3][3];        // [c][0..2] normalised centre, edge, corner
@@ -146,7 +154,13 @@ struct DevImage {
   int32_t* wp_grp;          // [ng][wp_grp_ints]
   int64_t wp_grp_ints;
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
-  int32_t* coef[3];         // wp*hp, footprint layout; int32 quantised, then float dequantised in place
+  // HF coefficients as decoded (hf_decode_kernel -> recon_tile_kernel): sparse entry lists per group, see kGroupEntriesCap.
+  uint32_t* centries;       // group g at centries + (g - centries_g0) * kGroupEntriesCap
+  int32_t centries_g0, pad2;
+  U32x2* cblk;             // [3][w8 * h8], valid at the origin cell of every varblock: .x = first entry of (block, channel) in its
+                            // group's list, .y = number of entries
+  int32_t* coef[3];         // wp*hp, footprint layout (generic path / debug taps only): int32 quantised, then float dequantised in place;
+                            // shares the third set of pixel-chunk planes with xyb2
   float* tmp[3];            // wp*hp
   float* xyb[3];            // wp*hp
   float* xyb2[3];           // wp*hp

@@ -27,10 +27,7 @@ __device__ const uint8_t d_log2cy[kNumStrategies] = {0, 0, 0, 0, 1, 2, 1, 0, 2, 
 __device__ const uint8_t d_nnz_ctx[64] = {0,   0,   31,  62,  62,  93,  93,  93,  93,  123, 123, 123, 123, 152, 152, 152, 152, 152, 152, 152, 152, 180,
                                           180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 180, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206,
                                           206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206, 206};
-// natural coefficient orders small enough for LDS: buckets 0..8, entry offsets
-__device__ const uint16_t d_order_lds_off[10] = {0, 64, 128, 384, 1408, 1536, 1792, 2304, 6400, 8448};
 
-__device__ __forceinline__ bool IsSpecialS(uint32_t s) { return (s >= 1 && s <= 3) || (s >= 12 && s <= 17); }
 __device__ __forceinline__ int CeilLog2D(uint32_t x) { return x <= 1 ? 0 : 32 - __clz(x - 1); }
 __device__ __forceinline__ int32_t UnpackSigned(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
 __device__ __forceinline__ void SetError(const DevImage& im, uint32_t bits) { atomicOr(im.status, bits); }
@@ -1026,25 +1023,19 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
   if (lane == 0) im.blk_count[g] = total;
 }
 
-__device__ __noinline__ void StoreViaGlobalOrder(const uint16_t* order, uint32_t k, uint32_t lng_log2, bool transposed, JXL_GLB int32_t* plane,
-                                                 int wp, int32_t value) {
-  const uint32_t p = order[k];
-  const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
-  const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-  plane[(size_t)ky * wp + kx] = value;
-}
-
 // One lane per group section (lane_stride spreads sections over wavefronts).  The loop decodes exactly one token per
 // iteration: the number-of-nonzeros token of a (block, channel) or one coefficient token.  Per-lane state that the
 // context model needs (non-zero counts of the row above / the cell to the left) is a 32-entry column buffer per
 // channel in LDS: col[x] = value of the last decoded block covering column x, which is both "above" and "left".
+// Output: every NON-ZERO coefficient becomes one 32-bit entry (scan position | value << 16) appended to the group's list -
+// sequential 4-byte stores, no coefficient order in the loop, nothing to pre-zero; the (first entry, count) pair of each
+// (block, channel) goes to cblk at the block's origin cell.  recon_tile_kernel scatters the entries into its LDS tile.
 // kRing: words of the per-lane bit window.  32 (top-up every 16 tokens, 8 queued descriptors: 288 B of LDS per lane) is the
-// faster loop for one frame; 16 (top-up every 8 tokens, 4 descriptors: 192 B per lane) lets two workgroups share a CU, which is
+// faster loop for one frame; 16 (top-up every 8 tokens, 4 descriptors: 192 B per lane) lets more workgroups share a CU, which is
 // what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
 // (>= the largest task.count of the launch).
 template <bool kLds, int kRing>
-__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots,
-                                                        const uint16_t* natural_orders_small) {
+__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots) {
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
   typedef LaneBitsT<kRing, kRing / 4> Bits;
@@ -1053,9 +1044,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const DevImage& im = imgs[task.image];
   const int per_wave = 64 / lane_stride;
   CodeTab<kLds> tab;
-  typename AS<kLds>::U16 lds_orders;
   typename AS<kLds>::U8 nnz_tab;
-  typename AS<kLds>::U16 order_off;
   JXL_LDS uint8_t* nzcol;
   JXL_LDS uint32_t* ring_base;
   JXL_LDS U2* descq;   // per lane: queue of the next kQ varblock descriptors, entry j at descq[(j & (kQ - 1)) * nslots + slot]
@@ -1067,22 +1056,13 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     nzcol = lds + off; off += (size_t)nslots * 96;
     if constexpr (kLds) {
       off = StageCode(lds, off, im.acode, tab, threadIdx.x, blockDim.x);
-      off = (off + 1) & ~(size_t)1;
-      JXL_LDS uint16_t* so = (JXL_LDS uint16_t*)(lds + off); off += 8448 * 2;
-      for (int i = threadIdx.x; i < 8448; i += blockDim.x) so[i] = natural_orders_small[i];
       JXL_LDS uint8_t* sn = lds + off; off += 64;
       if (threadIdx.x < 64) sn[threadIdx.x] = d_nnz_ctx[threadIdx.x];
-      JXL_LDS uint16_t* oo = (JXL_LDS uint16_t*)(lds + off); off += 20;
-      if (threadIdx.x < 10) oo[threadIdx.x] = d_order_lds_off[threadIdx.x];
-      lds_orders = so;
       nnz_tab = sn;
-      order_off = oo;
       __syncthreads();
     } else {
       GlobalCode(im.acode, tab);
-      lds_orders = natural_orders_small;
       nnz_tab = d_nnz_ctx;
-      order_off = d_order_lds_off;
     }
   }
   // Active lanes are the FIRST 64/lane_stride lanes of every wavefront: a wave64 whose upper 32 lanes are idle issues
@@ -1101,30 +1081,24 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const uint32_t ctx_offset = preset * nbc * 495;
   uint32_t err = preset >= (uint32_t)im.num_presets ? (uint32_t)kErrBitstream : 0u;
   uint32_t state = b.Read(32);
-  const int wp = im.wp;
-  const bool use_staged_orders = !im.custom_orders;
   const int gx = g % im.xg, gy = g / im.xg;
-  const size_t group_px = (size_t)gy * kGroupDim * wp + (size_t)gx * kGroupDim;
   // block descriptors: staged through a small LDS queue that is topped up together with the bit window
   const JXL_GLB U2* const list = (const JXL_GLB U2*)G(im.blk_list + (size_t)g * 2048);
   const uint32_t nblk = im.blk_count[g];
   JXL_LDS U2* const dq = descq + si;
   uint32_t bi = 0, dfilled = 0, it = 0;
+  // output: the group's entry list and the per-(block, channel) index (no global load may sit in the token loop - its wait would
+  // also wait for the stores - so every pointer is formed up front)
+  JXL_GLB uint32_t* const ent = G(im.centries) + (size_t)(g - im.centries_g0) * kGroupEntriesCap;
+  const uint32_t ncells = (uint32_t)im.w8 * (uint32_t)im.h8;
+  JXL_GLB U2* const cblk = (JXL_GLB U2*)G(im.cblk) + (size_t)(gy * kGroupBlocks) * im.w8 + (size_t)gx * kGroupBlocks;
+  const uint32_t w8 = (uint32_t)im.w8;
+  uint32_t epos = 0;
   // current block
-  uint32_t bx = 0, by = 0, lcx = 0, lcy = 0, log2c = 0, covered = 1, size = 64, ord = 0, lng_log2 = 3, ctxs = 0;
-  bool transposed = true;
-  size_t px0 = 0;
+  uint32_t bx = 0, by = 0, lcx = 0, log2c = 0, covered = 1, size = 64, ctxs = 0, cell = 0;
   // current (block, channel)
   int ci = 3;
   uint32_t nzeros = 0, k = 0, prev = 0, histo = 0;
-  uint32_t lorder = 0;                        // offset of a small natural order staged with the tables ...
-  bool order_staged = false;                  // ... else the order table is read from global memory (blocks of 128 and up, custom orders)
-  uint32_t pnext = 0;                         // staged order entry of coefficient k, fetched one token ahead
-  JXL_GLB int32_t* plane = nullptr;
-  // no global load may sit in the token loop (its wait would also wait for the stores): plane pointers up front
-  JXL_GLB int32_t* const coef0 = G(im.coef[0]);
-  JXL_GLB int32_t* const coef1 = G(im.coef[1]);
-  JXL_GLB int32_t* const coef2 = G(im.coef[2]);
   bool want_nz = true;
   while (!err) {
     if ((it & (kTop - 1)) == 0) {
@@ -1149,18 +1123,11 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 15 + ((ks - 16) >> 1) : 23 + ((ks - 32) >> 2));
         const uint32_t u = AnsGet(b, state, tab, histo + ((uint32_t)nnz_tab[nzl] + fctx) * 2 + prev);
         it++;
-        const uint32_t p = pnext;
-        const uint32_t k1 = k + 1 < size ? k + 1 : k;
-        pnext = lds_orders[lorder + (order_staged ? k1 : 0u)];
         bool leave = false;
         if (u) {
-          if (order_staged) {
-            const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
-            const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-            plane[__umul24(ky, wp) + kx] = UnpackSigned(u);   // ky < 256, wp < 2^24
-          } else {
-            StoreViaGlobalOrder(im.order[ord * 3 + (ci == 0 ? 1 : (ci == 1 ? 0 : 2))], k, lng_log2, transposed, plane, wp, UnpackSigned(u));
-          }
+          const int32_t v = UnpackSigned(u);
+          if (v != (int32_t)(int16_t)v) err |= kErrRange;
+          ent[epos++] = k | (uint32_t)v << 16;
           prev = 1;
           if (--nzeros == 0) { want_nz = true; ci++; leave = true; }
         } else {
@@ -1176,13 +1143,11 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       const U2 d = dq[__umul24(bi & (kQ - 1), nslots)];
       bi++;
       bx = d.x & 31; by = (d.x >> 5) & 31;
-      const uint32_t s = (d.x >> 10) & 31;
-      lcx = (d.x >> 15) & 7; lcy = (d.x >> 18) & 7; ord = (d.x >> 21) & 15;
+      lcx = (d.x >> 15) & 7;
+      const uint32_t lcy = (d.x >> 18) & 7;
       ctxs = d.y;
       log2c = lcx + lcy; covered = 1u << log2c; size = covered << 6;
-      lng_log2 = 3 + max(lcx, lcy);
-      transposed = !IsSpecialS(s) && lcy >= lcx;
-      px0 = group_px + (size_t)by * 8 * wp + (size_t)bx * 8;
+      cell = __umul24(by, w8) + bx;
       ci = 0;
     }
     const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
@@ -1211,33 +1176,23 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       const uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
       JXL_LDS uint8_t* const cc = col + __umul24(c * 32 + bx, nslots);
       for (uint32_t ix = 0; ix < (1u << lcx); ix++) cc[__umul24(ix, nslots)] = fill;
+      U2 rec;
+      rec.x = epos; rec.y = nzeros;
+      cblk[(size_t)c * ncells + cell] = rec;
       if (nzeros) {
         const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
         histo = ctx_offset + nbc * 37 + 458 * block_ctx;
-        order_staged = use_staged_orders && ord <= 8;
-        lorder = order_off[ord <= 8 ? ord : 0];
-        plane = (c == 0 ? coef0 : (c == 1 ? coef1 : coef2)) + px0;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
-        pnext = lds_orders[lorder + (order_staged ? k : 0u)];
         want_nz = false;
       } else {
         ci++;
       }
     } else {
-      const uint32_t p = pnext;
-      const uint32_t k1 = k + 1 < size ? k + 1 : k;
-      pnext = lds_orders[lorder + (order_staged ? k1 : 0u)];
       if (u) {
-        if (order_staged) {
-          const uint32_t r = p >> lng_log2, cc = p & ((1u << lng_log2) - 1);
-          const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-          plane[__umul24(ky, wp) + kx] = UnpackSigned(u);   // ky < 256, wp < 2^24
-        } else {
-          // blocks of 128 points and up / custom orders: the order entry comes from global memory.  Out of line on purpose: a load
-          // whose result merged into the common path made the compiler wait for ALL outstanding stores before every coefficient store.
-          StoreViaGlobalOrder(im.order[ord * 3 + c], k, lng_log2, transposed, plane, wp, UnpackSigned(u));
-        }
+        const int32_t v = UnpackSigned(u);
+        if (v != (int32_t)(int16_t)v) err |= kErrRange;
+        ent[epos++] = k | (uint32_t)v << 16;
         prev = 1;
         if (--nzeros == 0) { want_nz = true; ci++; }
       } else {
@@ -1594,20 +1549,20 @@ void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream
 size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 4) * 8; }
 
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words,
-                    size_t lds_bytes, const uint16_t* natural_orders_small, hipStream_t s) {
+                    size_t lds_bytes, hipStream_t s) {
   if (nwg <= 0) return;
   const size_t lane_bytes = (size_t)nslots * HfLaneLdsBytes(32);   // tables in global memory: always the wide window
   if (lds_bytes) {
     if (ring_words == 16) {
       RaiseLds((const void*)hf_decode_kernel<true, 16>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
     } else {
       RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
     }
   } else {
     RaiseLds((const void*)hf_decode_kernel<false, 32>, lane_bytes);
-    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride, nslots, natural_orders_small);
+    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride, nslots);
   }
 }
 

@@ -12,7 +12,7 @@ void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, 
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
-                    const uint16_t* natural_orders_small, hipStream_t s);
+                    hipStream_t s);
 void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical
@@ -27,6 +27,8 @@ void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStre
 void LaunchOrient(const uint8_t* src, uint8_t* dst, int w, int h, int px_bytes, int orientation, hipStream_t s);
 // kernels.hip
 void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipStream_t s);
+// sparse entry lists -> dense int32 coefficient planes, for the listed tiles (generic path) or every tile (debug taps)
+void LaunchExpandCoefficients(const DevImage* imgs, int nimg, bool all_tiles, int max_tiles, hipStream_t s);
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,
                               const float* llf_scale, hipStream_t s);
 // tile_kernels.hip

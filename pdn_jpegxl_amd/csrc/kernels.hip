@@ -5,6 +5,7 @@
 //   gaborish / epf<stage> / xyb_to_out
 // DESIGN.md has the data layout and the per-kernel roofline.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "dev_types.h"
 #include "kernels.h"
 
@@ -77,6 +78,65 @@ __global__ void cell_sigma_kernel(const DevImage* imgs) {
   const uint32_t n_listed_ = (im).status ? (im).status[1] : 0u;       \
   for (uint32_t li_ = blockIdx.x; li_ < n_listed_; li_ += gridDim.x) \
     for (int tile = (int)(im).tile_list[li_], once_ = 1; once_; once_ = 0)
+
+// The tiles a kernel of the generic path visits: the listed ones, or (all != 0: debug taps, multi-pass frames) every tile of the
+// decoded band.
+#define FOR_TILES(im, tile, all)                                                                    \
+  const uint32_t n_tiles_ = (all) ? (uint32_t)((im).wt * (im).ht) : ((im).status ? (im).status[1] : 0u); \
+  for (uint32_t li_ = blockIdx.x; li_ < n_tiles_; li_ += gridDim.x)                                 \
+    for (int tile = (all) ? (int)li_ : (int)(im).tile_list[li_], once_ = 1; once_; once_ = 0)
+
+// Dense int32 coefficient planes (footprint layout: coefficient (ky, kx) of a varblock at pixel (y0 + ky, x0 + kx)) for the tiles the
+// generic kernels handle, from the sparse entry lists hf_decode_kernel wrote: first zeros, then (a second launch: a varblock
+// larger than a tile reaches into other listed tiles) every entry of the varblocks that START in the tile.
+__global__ void expand_zero_kernel(const DevImage* imgs, int all) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (im.is_modular) return;
+  FOR_TILES(im, tile, all) {
+    const int tx = tile % im.wt, ty = tile / im.wt;
+    if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) continue;
+    for (int e = threadIdx.x; e < 4096; e += blockDim.x) {
+      const int x = tx * 64 + (e & 63), y = ty * 64 + (e >> 6);
+      if (x >= im.wp || y >= im.hp) continue;
+      const size_t i = (size_t)y * im.wp + x;
+      im.coef[0][i] = 0; im.coef[1][i] = 0; im.coef[2][i] = 0;
+    }
+  }
+}
+__global__ void expand_scatter_kernel(const DevImage* imgs, int all) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (im.is_modular) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
+  const size_t ncells = (size_t)im.w8 * im.h8;
+  FOR_TILES(im, tile, all) {
+    const int tx = tile % im.wt, ty = tile / im.wt;
+    if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) continue;
+    const uint32_t* entries = im.centries + (size_t)((ty >> 2) * im.xg + (tx >> 2) - im.centries_g0) * kGroupEntriesCap;
+    for (int pair = wave; pair < 192; pair += nwaves) {   // (cell, channel) pairs of the tile, one wavefront each
+      const int cell = pair & 63, c = pair >> 6;
+      const int bx = tx * 8 + (cell & 7), by = ty * 8 + (cell >> 3);
+      if (bx >= im.w8 || by >= im.h8) continue;
+      const uint32_t info = im.cellinfo[(size_t)by * im.w8 + bx];
+      if (!(info >> 31) || (info & 0x3FF00u)) continue;   // not the origin cell of a varblock
+      const uint32_t s = info & 0xFF, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+      const U32x2 blk = im.cblk[(size_t)c * ncells + (size_t)by * im.w8 + bx];
+      if (blk.y > 65536u || blk.x > kGroupEntriesCap - blk.y) continue;   // left unwritten by a failed section
+      const uint32_t q = c_quant_table[s], nq = im.dq_n[q];
+      const U32x2* scan = im.scan[q] + (size_t)c * nq;
+      const uint32_t lng = 3 + max(lcx, lcy);
+      const bool transposed = !IsSpecial(s) && lcy >= lcx;
+      int32_t* plane = im.coef[c] + (size_t)by * 8 * im.wp + (size_t)bx * 8;
+      for (uint32_t i = lane; i < blk.y; i += 64) {
+        const uint32_t ent = entries[blk.x + i], k = ent & 0xFFFFu;
+        if (k >= nq) continue;
+        const uint32_t p = scan[k].x;
+        const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
+        const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
+        if (ky < (8u << lcy) && kx < (8u << lcx)) plane[(size_t)ky * im.wp + kx] = (int32_t)ent >> 16;
+      }
+    }
+  }
+}
 
 __global__ void dequant_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
@@ -325,6 +385,12 @@ void LaunchLfPixelStages(const DevImage* imgs, int nimg, size_t max_cells, hipSt
   hipLaunchKernelGGL(lf_dequant_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
   hipLaunchKernelGGL(lf_smooth_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
   hipLaunchKernelGGL(cell_sigma_kernel, Grid2(max_cells, nimg), dim3(256), 0, s, imgs);
+}
+
+void LaunchExpandCoefficients(const DevImage* imgs, int nimg, bool all_tiles, int max_tiles, hipStream_t s) {
+  const dim3 g(all_tiles ? (unsigned)std::max(1, std::min(max_tiles, 8192)) : 128u, nimg);
+  hipLaunchKernelGGL(expand_zero_kernel, g, dim3(256), 0, s, imgs, all_tiles ? 1 : 0);
+  hipLaunchKernelGGL(expand_scatter_kernel, g, dim3(256), 0, s, imgs, all_tiles ? 1 : 0);
 }
 
 void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis_all, const float* basis_small,

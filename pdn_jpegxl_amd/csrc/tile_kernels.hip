@@ -191,6 +191,48 @@ __device__ __forceinline__ float DequantBias(int32_t v, float qb, float qb3) {
 }
 typedef int __attribute__((ext_vector_type(4))) I4v;
 
+// One sweep of the scatter: entries [0, total) of the tile's (block, channel) lists, found through the exclusive prefix `pre` over
+// the tile's 64 cells (only origin cells have entries).  Every entry is one non-zero quantised coefficient: its scan position k
+// selects {stored index, weight} from the per-table scan list, the stored index gives the coefficient's place in the varblock.
+// mul: channel multiplier (and, for the luma sweep of a chroma channel, the chroma-from-luma factor).  Adds into the zeroed tile
+// with ds_add_f32: a position receives at most one addend per sweep, two sweeps commute.
+__device__ __forceinline__ void ScatterSweep(float* cfc, const uint32_t* pre, const uint32_t* start, const uint32_t total, const uint32_t* entries,
+                                             const U32x2* const* csc, const uint32_t* cnq, const uint32_t* cmeta, const float* cscale,
+                                             int chan, float qb, float qb3, float mul, int tid) {
+  for (uint32_t e0 = 0; e0 < total; e0 += 512) {
+    uint32_t j[2], ent[2];
+    bool on[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t e = e0 + u * 256 + tid;
+      on[u] = e < total;
+      uint32_t jj = 0;
+#pragma unroll
+      for (int step = 32; step; step >>= 1) if (pre[jj + step] <= e) jj += step;
+      j[u] = jj;
+      ent[u] = on[u] ? entries[start[jj] + (e - pre[jj])] : 0u;
+    }
+    U32x2 se[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const uint32_t k = ent[u] & 0xFFFFu, nq = cnq[j[u]];
+      on[u] = on[u] && k < nq;   // a list that a failed section left half-written must not index past the table
+      se[u] = csc[j[u]][(size_t)chan * nq + (on[u] ? k : 0u)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      if (!on[u]) continue;
+      const uint32_t meta = cmeta[j[u]];
+      const uint32_t lng = meta & 15, p = se[u].x;
+      const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
+      const uint32_t ky = (meta & 16) ? cc : r, kx = (meta & 16) ? r : cc;
+      const int32_t v = (int32_t)ent[u] >> 16;
+      const float o = DequantBias(v, qb, qb3) * (cscale[j[u]] * mul) * __uint_as_float(se[u].y);
+      if (ky < 64 && kx < 64) atomicAdd(&cfc[((j[u] >> 3) * 8 + ky) * kLP + (j[u] & 7) * 8 + kx], o);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
                                                              const float* llf_scale) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
@@ -198,9 +240,14 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
   float* B816 = cfc + kTS * kLP;                       // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
   float* cscale = B816 + 320;                          // 64   per cell: inv_global_scale / raw quant of its varblock
   uint32_t* ci = (uint32_t*)(cscale + 64);             // 64   cell info
-  uint32_t* cmeta = ci + 64;                           // 64   log2 of the table pitch | transposed << 4 | origin cell: 1 << 16 | lcx << 8 | lcy << 12
+  uint32_t* cmeta = ci + 64;                           // 64   log2 of the table pitch | transposed << 4
   uint32_t* cnq = cmeta + 64;                          // 64   entries per channel of the cell's dequant table
-  const float** cw = (const float**)(cnq + 64);        // 64   table base + offset of the cell inside its varblock
+  uint32_t* cpre = cnq + 64;                           // 64   exclusive prefix of the entry counts, own channel ...
+  uint32_t* cstart = cpre + 64;                        // 64   ... and where each origin cell's entries start in the group's list
+  uint32_t* cpre_y = cstart + 64;                      // 64   the same for the luma lists (chroma from luma)
+  uint32_t* cstart_y = cpre_y + 64;                    // 64
+  uint32_t* ctot = cstart_y + 64;                      // 2 (+2 pad)  totals
+  const U32x2** csc = (const U32x2**)(ctot + 4);       // 64   scan list of the cell's quant table
   const DevImage& im = imgs[blockIdx.y];
   const int tile = blockIdx.x / 3, cidx = blockIdx.x % 3;
   if (tile >= im.wt * im.ht) return;
@@ -208,22 +255,11 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
   const int tx = tile % im.wt, ty = tile / im.wt;
   if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
   const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
-  // The quantised coefficients (addresses depend only on the tile) are requested first: their latency overlaps the two dependent
-  // round trips of the cell-table prologue below.
   const int wp = im.wp, hp = im.hp;
-  I4v qv[4], qvy[4];
+  // the tile starts as zeros: only non-zero coefficients exist in the entry lists
   {
-    const int32_t* qc = im.coef[c];
-    const int32_t* qy = im.coef[1];
-    const int gx = tx * kTS + (tid & 15) * 4;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int gy = ty * kTS + (tid >> 4) + 16 * it;
-      const size_t g = (size_t)min(gy, hp - 1) * wp + min(gx, wp - 4);
-      qv[it] = *(const I4v*)(qc + g);
-      if (c != 1) qvy[it] = *(const I4v*)(qy + g);
-      else qvy[it] = I4v{0, 0, 0, 0};
-    }
+    float4* z = (float4*)cfc;
+    for (int i = tid; i < kTS * kLP / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   int bad = 0;
   uint32_t info0 = 0;
@@ -232,9 +268,13 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
     const bool inside = cx < im.w8 && cy < im.h8;
     const size_t cell_g = (size_t)min(cy, im.h8 - 1) * im.w8 + min(cx, im.w8 - 1);
+    const size_t ncells = (size_t)im.w8 * im.h8;
     const uint32_t info_g = im.cellinfo[cell_g];
     const uint32_t rq_g = im.rawq[cell_g];
     const float lf_g = im.lf_final[c][cell_g];
+    const U32x2 blk_g = im.cblk[(size_t)c * ncells + cell_g];
+    U32x2 blk_y = blk_g;
+    if (c != 1) blk_y = im.cblk[ncells + cell_g];
     const uint32_t info = inside ? info_g : 0u;
     const uint32_t rqv = inside ? rq_g : 1u;
     lfv = inside ? lf_g : 0.f;
@@ -252,12 +292,26 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     const uint32_t q = t_quant_table[valid ? (info & 0xFF) : 0];
     const uint32_t rq_origin = (uint32_t)__shfl((int)rqv, valid ? tid - iy * 8 - ix : tid);
     const uint32_t lng = 3 + max(lcx, lcy);
-    const bool transposed = lcy > lcx;   // square DCT tables are symmetric: row-major walks give consecutive lanes consecutive weights
+    const bool transposed = lcy >= lcx;   // the stored layout of a varblock has its longer side horizontal (squares: transposed too)
     ci[tid] = info;
     cscale[tid] = im.inv_global_scale / (float)rq_origin;
-    cmeta[tid] = lng | (transposed ? 16u : 0u) | ((valid && ix == 0 && iy == 0) ? (1u << 16) | ((uint32_t)lcx << 8) | ((uint32_t)lcy << 12) : 0u);
+    cmeta[tid] = lng | (transposed ? 16u : 0u);
     cnq[tid] = im.dq_n[q];
-    cw[tid] = im.dq[q] + (transposed ? ((uint32_t)(8 * ix) << lng) + 8 * iy : ((uint32_t)(8 * iy) << lng) + 8 * ix);
+    csc[tid] = im.scan[q];
+    // entry lists of the varblocks that start in this tile; a list a failed section left unwritten is treated as empty
+    const bool origin = valid && ix == 0 && iy == 0;
+    uint32_t n_own = origin ? blk_g.y : 0u, n_y = (origin && c != 1) ? blk_y.y : 0u;
+    if (n_own > 65536u || blk_g.x > kGroupEntriesCap - n_own) n_own = 0;
+    if (n_y > 65536u || blk_y.x > kGroupEntriesCap - n_y) n_y = 0;
+    uint32_t s_own = n_own, s_y = n_y;   // inclusive scans over the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t a = (uint32_t)__shfl_up((int)s_own, d), bq = (uint32_t)__shfl_up((int)s_y, d);
+      if (tid >= d) { s_own += a; s_y += bq; }
+    }
+    cpre[tid] = s_own - n_own; cstart[tid] = blk_g.x;
+    cpre_y[tid] = s_y - n_y; cstart_y[tid] = blk_y.x;
+    if (tid == 63) { ctot[0] = s_own; ctot[1] = s_y; }
   }
   for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
   if (__syncthreads_or(bad)) {
@@ -292,57 +346,16 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     }
     if (valid) cfc[(oy * 8 + iy) * kLP + ox * 8 + ix] = acc * sc;
   }
-  // ---- dequantisation (+ chroma from luma)
+  // ---- dequantisation (+ chroma from luma) of the non-zero coefficients, scattered to their places
   {
     const size_t tile_cfl = (size_t)ty * im.wt + tx;
     const float cfl = c == 1 ? 0.f : (c == 0 ? im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor
                                               : im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor);
-    const float qbc = im.qbias[c], qb1 = im.qbias[1], qb3 = im.qbias[3];
     const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
-    const int x4 = (tid & 15) * 4, yb = tid >> 4;
-    const int gx = tx * kTS + x4;
-    const int xx = x4 & 7, ccol = x4 >> 3;
-#pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int y = yb + 16 * it;
-      const int gy = ty * kTS + y;
-      const bool inside = gx < wp && gy < hp;
-      const int cell = (y >> 3) * 8 + ccol;
-      const uint32_t meta = cmeta[cell];
-      const uint32_t nq = cnq[cell];
-      const float* wt = cw[cell];
-      const float scale = cscale[cell];
-      const uint32_t lng = meta & 15;
-      const bool transposed = meta & 16;
-      const int yy = y & 7;
-      const I4v v = qv[it], vy = qvy[it];
-      float w[4], wy[4];
-      if (!transposed) {
-        const uint32_t idx = ((uint32_t)yy << lng) + xx;
-        const float4 t = *(const float4*)(wt + (size_t)c * nq + idx);
-        w[0] = t.x; w[1] = t.y; w[2] = t.z; w[3] = t.w;
-        if (c != 1) { const float4 u = *(const float4*)(wt + (size_t)nq + idx); wy[0] = u.x; wy[1] = u.y; wy[2] = u.z; wy[3] = u.w; }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const uint32_t idx = ((uint32_t)(xx + j) << lng) + yy;
-          w[j] = wt[(size_t)c * nq + idx];
-          if (c != 1) wy[j] = wt[(size_t)nq + idx];
-        }
-      }
-      int nskip = 0;   // leading LLF positions of this group of four (written by wavefront 0)
-      if ((meta >> 16) & 1) {
-        const int cx = 1 << ((meta >> 8) & 7), cy = 1 << ((meta >> 12) & 7);
-        if (yy < cy) nskip = min(max(cx - xx, 0), 4);
-      }
-      const int vv[4] = {v.x, v.y, v.z, v.w}, vvy[4] = {vy.x, vy.y, vy.z, vy.w};
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        float o = DequantBias(vv[j], qbc, qb3) * (scale * dm) * w[j];
-        if (c != 1) o += cfl * (DequantBias(vvy[j], qb1, qb3) * scale * wy[j]);
-        if (j >= nskip) cfc[y * kLP + x4 + j] = inside ? o : 0.f;
-      }
-    }
+    // the tile's group (four tiles per group side)
+    const uint32_t* entries = im.centries + (size_t)((ty >> 2) * im.xg + (tx >> 2) - im.centries_g0) * kGroupEntriesCap;
+    ScatterSweep(cfc, cpre, cstart, ctot[0], entries, csc, cnq, cmeta, cscale, c, im.qbias[c], im.qbias[3], dm, tid);
+    if (c != 1 && cfl != 0.f) ScatterSweep(cfc, cpre_y, cstart_y, ctot[1], entries, csc, cnq, cmeta, cscale, 1, im.qbias[1], im.qbias[3], cfl, tid);
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, l16 = tid & 15, lq = lane >> 4;
@@ -718,7 +731,7 @@ __global__ void out_only_kernel(const DevImage* imgs) {
 
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, hipStream_t s) {
-  const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 4 + 128) * 4;   // tile, B816, four per-cell words, per-cell table pointers
+  const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 8 + 4 + 128) * 4;   // tile, B816, eight per-cell words, totals, per-cell scan-list pointers
   hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale);
 }
 

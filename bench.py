@@ -1,60 +1,207 @@
 #!/usr/bin/env python3
 """Benchmark of the JPEG XL decode hot path on MI355X (contract: README of the build driver).
 
-One *step* = one pass of the hot path over one batch: B copies of the 3840x2160 RGBA8 lossy VarDCT (distance 1.0)
-synthetic image (BASELINE.json configs[1]) decoded from HBM-resident .jxl bytes to HBM-resident RGBA8, through the
-C-ABI batch entry point jxlhip_decode_batch (host header parsing included in the timed region).
-value = megapixels decoded per second, whole job (all ranks).  With --gpus N each rank decodes its own batch
-(weak scaling; independent images shard with no data-path collective — DESIGN.md "Multi-GPU").
+Workloads (--workload):
+  4k        (default; BASELINE.json configs[1]) one *step* = one pass of the hot path over one batch: B 3840x2160 RGBA8 lossy VarDCT
+            (distance 1.0) images - eight DISTINCT synthetic images, tests/golden/bench_index.json, repeated - decoded from
+            HBM-resident .jxl bytes to HBM-resident RGBA8 through the C-ABI batch entry point jxlhip_decode_batch (host header
+            parsing included in the timed region).  With --gpus N every rank decodes its own batch: weak scaling, independent images
+            shard with no data-path collective (DESIGN.md "Multi-GPU").
+  16k-bands (configs[2]) one step = ONE 16384x16384 RGBA8 lossy frame decoded by all ranks together: every rank decodes its band of
+            256x256-group rows and the bands are gathered with one RCCL all_gather over xGMI.  Strong scaling.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel = the one with the most time per batch among lf_ans / hf_decode / alpha_ans / alpha_finish /
-                recon_tile / filter_gab_epf1, bound = HBM; achieved = algorithmic bytes of ONE launch (frames in that launch *
-                (jxl bytes + W*H*4)) / the average HIP-event duration of one launch
-  cpu_baseline  the CPU oracle (kind "port"; libjxl is not available offline) on this box's host cores, rank 0 only
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run, one
+process per GPU, before this process touches a GPU) and exits with their code.
+
+value = megapixels decoded per second, whole job (all ranks).  Extra objects on the JSON line:
+  roofline      dominant kernel = the stage with the most time per step; bound = HBM; achieved = algorithmic bytes of ONE launch
+                (frames in that launch * (jxl bytes + W*H*4)) / the average HIP-event duration of one launch
+  cpu_baseline  the CPU oracle (kind "port": libjxl is looked for with find_library and timed if present) built -O3 -march=native
+                on this box and run on its host cores, rank 0 at N = 1 only
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FIXTURE = os.path.join(ROOT, "tests", "golden", "synth_3840x2160_seed2_d1.jxl")
+GOLD = os.path.join(ROOT, "tests", "golden")
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def cpu_baseline(data, width, height, seconds_budget=12.0):
-    """Times the CPU oracle on the same file (bounded sample).  Only this leg touches oracle/."""
+def bench_files():
+    """The eight distinct 4K inputs, in the order of their seeds."""
+    index = json.load(open(os.path.join(GOLD, "bench_index.json")))
+    names = sorted(index, key=lambda n: index[n]["seed"])
+    return [open(os.path.join(GOLD, n + ".jxl"), "rb").read() for n in names]
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
+def _libjxl_probe(data, width, height, threads):
+    """if a libjxl is discoverable at run time, time it on the same file; otherwise say that it is not there."""
+    import ctypes as C
+    import ctypes.util
+    path = ctypes.util.find_library("jxl")
+    if not path:
+        return "not found by ctypes.util.find_library('jxl') on this box (offline image)"
+    try:
+        J = C.CDLL(path)
+        tpath = ctypes.util.find_library("jxl_threads")
+        T = C.CDLL(tpath) if tpath else None
+
+        class PixelFormat(C.Structure):
+            _fields_ = [("num_channels", C.c_uint32), ("data_type", C.c_int), ("endianness", C.c_int), ("align", C.c_size_t)]
+        J.JxlDecoderCreate.restype = C.c_void_p
+        J.JxlDecoderCreate.argtypes = [C.c_void_p]
+        for fn in ("JxlDecoderSubscribeEvents", "JxlDecoderSetInput", "JxlDecoderProcessInput", "JxlDecoderSetImageOutBuffer",
+                   "JxlDecoderSetParallelRunner"):
+            getattr(J, fn).restype = C.c_int
+        J.JxlDecoderSubscribeEvents.argtypes = [C.c_void_p, C.c_int]
+        J.JxlDecoderSetInput.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        J.JxlDecoderProcessInput.argtypes = [C.c_void_p]
+        J.JxlDecoderSetImageOutBuffer.argtypes = [C.c_void_p, C.POINTER(PixelFormat), C.c_void_p, C.c_size_t]
+        J.JxlDecoderCloseInput.argtypes = [C.c_void_p]
+        J.JxlDecoderDestroy.argtypes = [C.c_void_p]
+        runner = None
+        if T is not None:
+            T.JxlThreadParallelRunnerCreate.restype = C.c_void_p
+            T.JxlThreadParallelRunnerCreate.argtypes = [C.c_void_p, C.c_size_t]
+            runner = T.JxlThreadParallelRunnerCreate(None, threads)
+        fmt = PixelFormat(4, 2, 0, 0)   # RGBA, JXL_TYPE_UINT8, native endianness, tight rows (DecoderContext.cpp:22)
+        out = (C.c_uint8 * (width * height * 4))()
+        best = None
+        for _ in range(3):
+            dec = J.JxlDecoderCreate(None)
+            if runner:
+                J.JxlDecoderSetParallelRunner.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+                J.JxlDecoderSetParallelRunner(dec, C.cast(T.JxlThreadParallelRunner, C.c_void_p), runner)
+            J.JxlDecoderSubscribeEvents(dec, 0x1000)   # JXL_DEC_FULL_IMAGE
+            t0 = time.perf_counter()
+            J.JxlDecoderSetInput(dec, data, len(data))
+            J.JxlDecoderCloseInput(dec)
+            while True:
+                st = J.JxlDecoderProcessInput(dec)
+                if st == 5:     # JXL_DEC_NEED_IMAGE_OUT_BUFFER
+                    J.JxlDecoderSetImageOutBuffer(dec, C.byref(fmt), out, len(out))
+                elif st in (0, 0x1000):
+                    break
+                elif st in (1, 2):
+                    raise RuntimeError("libjxl status %d" % st)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+            J.JxlDecoderDestroy(dec)
+        return {"path": path, "mp_per_s": round(width * height / best / 1e6, 2), "threads": threads}
+    except Exception as e:   # a library that is there but unusable is reported, not hidden
+        return "found %s but could not time it: %s" % (path, e)
+
+
+def cpu_baseline(files, width, height, seconds_budget=14.0):
+    """Times the CPU oracle on the same files (bounded sample).  Only this leg touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    cores = os.cpu_count() or 1
-    threads = min(cores, 32)
-    O.decode(data, num_threads=threads)  # warm-up (page-in, table init)
+    build = "-O3 -march=native, built on this box"
+    try:
+        O.use(O.build_native())
+    except Exception as e:   # no compiler on the box: the portable build that travelled with the repo
+        build = "portable -O2 build (native build failed: %s)" % str(e)[:80]
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    data = files[0]
+    O.decode(data, num_threads=min(usable, 16))   # warm-up (page-in, table init)
+    # the oracle threads over the 135 pass groups of a frame: find the thread count that is fastest on this box, then sample with it
+    cands = sorted({t for t in (16, 32, 64, 128, usable) if t <= usable} or {usable})
+    probe = {}
+    for t in cands:
+        t0 = time.perf_counter()
+        O.decode(data, num_threads=t)
+        probe[t] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
     times = []
     t_end = time.perf_counter() + seconds_budget
-    while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 8):
+    k = 0
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 16):
         t0 = time.perf_counter()
-        O.decode(data, num_threads=threads)
+        O.decode(files[k % len(files)], num_threads=threads)
         times.append(time.perf_counter() - t0)
-    best = min(times)
-    return {"value": round(width * height / best / 1e6, 3), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": "%d decodes of the same 3840x2160 RGBA8 d=1.0 file with the CPU oracle (%d threads over groups), best of %d"
-                      % (len(times), threads, len(times)), "host_cores": cores, "libjxl": "unavailable (offline)"}
+        k += 1
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(width * height / med / 1e6, 3), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": "%d decodes over the %d distinct 3840x2160 RGBA8 d=1.0 files with the CPU oracle (%s; %d threads over groups, the fastest of %s), median"
+                      % (len(times), len(files), build, threads, cands),
+            "host_cores_usable": usable, "host_cores_total": os.cpu_count(), "best_mp_per_s": round(width * height / min(times) / 1e6, 3),
+            "libjxl": _libjxl_probe(data, width, height, threads)}
+
+
+# ------------------------------------------------------------------------------------------------ launcher
+def launch_ranks(args):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as children.  Nothing here touches a GPU."""
+    import torch
+    rehearsal = os.environ.get("JXLHIP_BENCH_REHEARSAL") == "1"
+    visible = torch.cuda.device_count()   # counting devices does not initialise the GPU on this image
+    if visible < args.gpus and not rehearsal:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, visible), file=sys.stderr)
+        return 2
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def stage_kernels(B, chunk):
+    nchunks = (B + chunk - 1) // chunk
+    return {"lf_ans": ("lf_ans_kernel", 1, B), "hf_decode": ("hf_decode_kernel", 1, B), "alpha_ans": ("alpha_ans_kernel", 1, B),
+            "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile_kernel", nchunks, min(B, chunk)),
+            "filters+output": ("filter_stream_kernel", nchunks, min(B, chunk))}
+
+
+def roofline_object(stage_ms, kernels, alg_bytes_per_image):
+    """The dominant kernel of the run (most time per step) against the HBM roof."""
+    dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))
+    kname, launches, imgs_per_launch = kernels[dom]
+    dom_ms = stage_ms.get(dom, 0.0) / launches          # average duration of ONE launch of that kernel (HIP events on its stream)
+    alg_bytes = imgs_per_launch * alg_bytes_per_image
+    # HBM traffic of that kernel from the newest committed PMC passes (profiles/r*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    # --pmc WRITE_SIZE in separate runs, gfx950 correction 2*FETCH + WRITE per the micro-architecture guide), scaled to one launch
+    traffic = None
+    try:
+        pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+        key = [k for k in pmc["kernels"] if k.startswith(kname)][0]
+        traffic = int(pmc["kernels"][key]["hbm_bytes_per_image_corrected"] * imgs_per_launch)
+    except Exception:
+        pass
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": int(alg_bytes),
+            "launch_ms": round(dom_ms, 4), "launches_per_step": launches, "images_per_launch": imgs_per_launch}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=["4k", "16k-bands"], default=os.environ.get("JXLHIP_BENCH_WORKLOAD", "4k"))
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "384")))
+    ap.add_argument("--frame-size", type=int, default=16384, help="side of the 16k-bands frame (smaller for rehearsals)")
     ap.add_argument("--lane-stride", type=int, default=0)
+    ap.add_argument("--distinct", type=int, default=8, help="how many of the eight distinct 4K images the batch cycles through (experiments)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="synchronise after every step (no cross-batch overlap)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 20 if args.workload == "4k" else 10
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     import torch
     import torch.distributed as dist
@@ -63,11 +210,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
     # Rehearsal hook for a one-GPU box (the real multi-GPU run uses one device per rank and RCCL): JXLHIP_BENCH_REHEARSAL=1 puts
-    # every rank on device 0 and runs the (tiny, non-data-path) collectives over gloo.
+    # every rank on device 0 and runs the collectives over gloo (RCCL refuses two ranks on one device).
     rehearsal = os.environ.get("JXLHIP_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local_rank = 0
@@ -76,28 +226,59 @@ def main():
         dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     coll_dev = "cpu" if rehearsal else "cuda"
 
-    data = open(FIXTURE, "rb").read()
-    info = api.peek(data)
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    dec = api.Decoder(local_rank)
+    dec.set_option("lane_stride", args.lane_stride)
+    if args.workload == "16k-bands":
+        line = run_bands(args, dec, rank, world, rehearsal, coll_dev, fence, max_over_ranks)
+    else:
+        line = run_4k(args, dec, rank, world, coll_dev, fence, max_over_ranks)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_4k(args, dec, rank, world, coll_dev, fence, max_over_ranks):
+    import torch
+    import torch.distributed as dist
+    from pdn_jpegxl_amd import api
+    distinct = bench_files()[: max(1, args.distinct)]
+    info = api.peek(distinct[0])
     W, H, C = info.width, info.height, info.num_channels
     # Batch per GPU: as many frames as the entropy stages can keep in flight (their time per batch is nearly constant), bounded by
-    # HBM: three pipeline slots of ~165 MB of entropy-stage state per frame, two output sets, and the shared pixel-stage planes.
+    # HBM: three pipeline slots of entropy-stage state per frame (worst-case entry lists, alpha, LF), two output sets, and the shared
+    # pixel-stage planes.
     free_b = torch.cuda.mem_get_info()[0]
-    fit = int((free_b * 0.88 - 26e9) / (3 * 165e6 + 2 * W * H * C))
+    fit = int((free_b * 0.88 - 40e9) / (3 * 165e6 + 2 * W * H * C))
     B = max(1, min(args.batch, fit))
     if world > 1:
         t = torch.tensor([B], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         B = int(t.item())
-    dec = api.Decoder(local_rank)
-    dec.set_option("lane_stride", args.lane_stride)
     # inputs resident in HBM before the timed region (padded: the bit readers fetch whole 32-bit words)
-    src = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
-    src[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    srcs = []
+    for d in distinct:
+        s = torch.zeros(len(d) + 64, dtype=torch.uint8, device="cuda")
+        s[: len(d)] = torch.frombuffer(bytearray(d), dtype=torch.uint8).cuda()
+        srcs.append(s)
+    files = [distinct[(i + rank) % len(distinct)] for i in range(B)]
+    dev_in = [srcs[(i + rank) % len(distinct)].data_ptr() for i in range(B)]
     outs = [torch.empty(W * H * C, dtype=torch.uint8, device="cuda") for _ in range(B)]
-    files = [data] * B
-    dev_in = [src.data_ptr()] * B
     dev_out = [o.data_ptr() for o in outs]
-
     # two output sets: consecutive asynchronous batches must not write the same buffers
     outs2 = [torch.empty(W * H * C, dtype=torch.uint8, device="cuda") for _ in range(B)]
     dev_out2 = [o.data_ptr() for o in outs2]
@@ -109,12 +290,6 @@ def main():
         counter[0] += 1
         st = dec.decode_batch(files, dev_out if counter[0] & 1 else dev_out2, dev_in, synchronize=args.sync_steps)
         assert all(s == 0 for s in st), st
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(3):      # setup: populate the decoder's three workspace slots (allocation is not decode work)
         step()
@@ -132,10 +307,7 @@ def main():
     elapsed = time.perf_counter() - t0
     stage_sum, nb = dec.stage_totals(reset=True)
     assert nb == args.steps, (nb, args.steps)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed)
 
     # host cost of submitting one batch into an idle pipeline (header parsing of B files, table blob, enqueue), outside the timed region:
     # it has to stay below the GPU time per step for the step to be GPU-bound
@@ -145,73 +317,134 @@ def main():
         dec.decode_batch(files, dev_out, dev_in, synchronize=False)
         host_ms.append((time.perf_counter() - th) * 1e3)
         dec.finish()
-
     # single-image latency (B = 1), outside the timed region
     lat = []
     for _ in range(3):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        dec.decode_batch([data], dev_out[:1], dev_in[:1], synchronize=True)
+        dec.decode_batch(files[:1], dev_out[:1], dev_in[:1], synchronize=True)
         lat.append((time.perf_counter() - t1) * 1e3)
     lat_stages = dec.stage_times()
+    if rank != 0:
+        return None
+    mp = W * H / 1e6
+    stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+    chunk = dec.set_option("query_pixel_chunk", 0) or B
+    mean_jxl = sum(len(f) for f in files) / len(files)
+    line = {
+        "metric": "megapixels/sec decode (4K lossy VarDCT)",
+        "value": round(world * B * args.steps * mp / elapsed, 2),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "3840x2160 RGBA8 lossy VarDCT (distance=1.0) decode, HBM-resident .jxl -> HBM RGBA8",
+                   "batch_per_gpu": B, "distinct_images": len(distinct), "jxl_bytes_mean": int(mean_jxl), "groups_per_image": info.num_groups,
+                   "lane_stride": args.lane_stride or "auto", "async_steps": not args.sync_steps,
+                   "parallelism": "images sharded across ranks, no data-path collective"},
+        "roofline": roofline_object(stage_ms, stage_kernels(B, chunk), int(mean_jxl) + W * H * C),
+        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+        "stage_ms_note": "HIP-event time per stage on its own stream; three streams overlap, so the stages add up to more than ms_per_step",
+        "host_submit_ms_per_batch": round(min(host_ms), 3),
+        "single_image": {"latency_ms": round(min(lat), 3), "mp_per_s": round(mp / (min(lat) * 1e-3), 2),
+                         "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()}},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(distinct, W, H)
+    return line
 
-    if rank == 0:
-        mp = W * H / 1e6
-        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        # stage -> (kernel, launches per batch, images per launch).  The pixel stages run in chunks of `chunk` frames that share one set
-        # of float planes, so their kernels are launched ceil(B / chunk) times per batch; the entropy kernels cover the whole batch.
-        chunk = dec.set_option("query_pixel_chunk", 0) or B
-        nchunks = (B + chunk - 1) // chunk
-        kernels = {"lf_ans": ("lf_ans_kernel", 1, B), "hf_decode": ("hf_decode_kernel", 1, B), "alpha_ans": ("alpha_ans_kernel", 1, B),
-                   "alpha_finish": ("alpha_finish_kernel", 1, B), "reconstruct": ("recon_tile_kernel", nchunks, min(B, chunk)),
-                   "filters+output": ("filter_gab_epf1_kernel", nchunks, min(B, chunk))}
-        # the dominant kernel of this run: most time per batch
-        dom = max(kernels, key=lambda k: stage_ms.get(k, 0.0))
-        kname, launches, imgs_per_launch = kernels[dom]
-        dom_ms = stage_ms.get(dom, 0.0) / launches          # average duration of ONE launch of that kernel (HIP events on its stream)
-        alg_bytes = imgs_per_launch * (len(data) + W * H * C)
-        # HBM traffic of that kernel from the newest committed PMC passes (profiles/r*_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE in separate runs, gfx950 correction 2*FETCH + WRITE per the micro-architecture guide), scaled to one launch
-        traffic = None
-        try:
-            import glob
-            pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-            key = [k for k in pmc["kernels"] if k.startswith(kname)][0]
-            traffic = int(pmc["kernels"][key]["hbm_bytes_per_image_corrected"] * imgs_per_launch)
-        except Exception:
-            pass
-        achieved = alg_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        line = {
-            "metric": "megapixels/sec decode (4K lossy VarDCT)",
-            "value": round(world * B * args.steps * mp / elapsed, 2),
-            "unit": "MP/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "3840x2160 RGBA8 lossy VarDCT (distance=1.0) decode, HBM-resident .jxl -> HBM RGBA8",
-                       "batch_per_gpu": B, "jxl_bytes": len(data), "groups_per_image": info.num_groups,
-                       "lane_stride": args.lane_stride or "auto", "async_steps": not args.sync_steps, "parallelism": "images sharded across ranks, no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": round(dom_ms, 4), "launches_per_step": launches,
-                         "images_per_launch": imgs_per_launch},
-            "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
-            "host_submit_ms_per_batch": round(min(host_ms), 3),
-            "single_image": {"latency_ms": round(min(lat), 3), "mp_per_s": round(mp / (min(lat) * 1e-3), 2),
-                             "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()}},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(data, W, H)
-        print(json.dumps(line), flush=True)
+
+def make_big_frame(n):
+    """An n x n RGBA8 lossy frame (distance 1.0) written by the product's own encoder from tiled synthetic content."""
+    import numpy as np
+    from pdn_jpegxl_amd import api
+    from pdn_jpegxl_amd.synth import synth
+    base = synth(3840, 2160, 3)
+    img = np.tile(base, (n // 2160 + 1, n // 3840 + 1, 1))[:n, :n]
+    bgra = np.ascontiguousarray(img[..., [2, 1, 0, 3]])
+    return api.save_image(bgra, distance=1.0)
+
+
+def run_bands(args, dec, rank, world, rehearsal, coll_dev, fence, max_over_ranks):
+    import torch
+    import torch.distributed as dist
+    from pdn_jpegxl_amd import api
+    from pdn_jpegxl_amd.distributed import BandDecoder
+    n = args.frame_size
+    # rank 0 writes the frame, everybody gets the same bytes
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        if rank == 0:
+            data = make_big_frame(n)
+            size = torch.tensor([len(data)], dtype=torch.int64, device=coll_dev)
+        else:
+            size = torch.zeros(1, dtype=torch.int64, device=coll_dev)
+        dist.broadcast(size, 0)
+        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=coll_dev)
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(data), dtype=torch.uint8))
+        dist.broadcast(buf, 0)
+        data = bytes(buf.cpu().numpy().tobytes())
+    else:
+        data = make_big_frame(n)
+    info = api.peek(data)
+    W, H, C = info.width, info.height, info.num_channels
+    bd = BandDecoder(dec, data, rank, world, gather_device=coll_dev)   # the codestream goes to HBM once, before the timed region
+    for _ in range(2 + args.warmup):
+        bd.step()
+    dec.stage_totals(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bd.step()
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    stage_sum, nb = dec.stage_totals(reset=True)
+    # where one band's time goes (rank 0, stage times of the last step), and the gather alone
+    band_stages = dec.stage_times()
+    tg = []
+    for _ in range(3):
+        fence()
+        t1 = time.perf_counter()
+        bd.gather()
+        torch.cuda.synchronize()
+        tg.append((time.perf_counter() - t1) * 1e3)
+    if rank != 0:
+        return None
+    mp = W * H / 1e6
+    stage_ms = {k: v / max(1, nb) for k, v in stage_sum.items()}
+    rows = bd.rows
+    frac = rows / H if H else 1.0
+    kernels = {"lf_ans": ("lf_ans_kernel", 1, frac), "hf_decode": ("hf_decode_kernel", 1, frac), "alpha_ans": ("alpha_ans_kernel", 1, frac),
+               "alpha_finish": ("alpha_finish_kernel", 1, frac), "reconstruct": ("recon_tile_kernel", 1, frac),
+               "filters+output": ("filter_stream_kernel", 1, frac)}
+    return {
+        "metric": "megapixels/sec decode (16384x16384 lossy VarDCT frame, band-sharded)",
+        "value": round(args.steps * mp / elapsed, 2),
+        "unit": "MP/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "%dx%d RGBA8 lossy VarDCT (distance=1.0) frame, 256x256 groups sharded by group rows across ranks, RCCL all_gather of the bands"
+                               % (W, H), "jxl_bytes": len(data), "groups": info.num_groups, "band_rows_rank0": rows,
+                   "collective": "gloo (one-GPU rehearsal)" if rehearsal else ("all_gather over RCCL" if world > 1 else "none (one rank)"),
+                   "parallelism": "bands%d" % world},
+        "roofline": roofline_object(stage_ms, kernels, len(data) + W * H * C),
+        "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+        "band_stage_ms_rank0": {k: round(v, 4) for k, v in band_stages.items()},
+        "gather_ms": round(min(tg), 3),
+    }
 
 
 if __name__ == "__main__":

@@ -35,7 +35,7 @@ def build(force=False, verbose=False):
         o = os.path.join(objdir, src + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-x", "hip", "-c", s, "-o", o]
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-x", "hip", "-c", s, "-o", o] + os.environ.get("JXLHIP_EXTRA_CFLAGS", "").split()
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

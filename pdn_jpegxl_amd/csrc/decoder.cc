@@ -148,7 +148,6 @@ struct JxlHipDecoder {
   uint8_t* li_dev = nullptr; uint8_t* li_host = nullptr; size_t li_cap = 0;
   void EnsureLoadImageBuffers(size_t bytes);
   int lane_stride_override = 0;
-  int hf_ring_override = 0;
   int hf_stride_override = 0;   // experiment knob: lane stride of the HF kernel only
   bool debug_taps = false;
   // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
@@ -211,7 +210,6 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     HIP_OK(hipMemcpy(d_scan[q], sl.data(), sl.size() * sizeof(U32x2), hipMemcpyHostToDevice));
   }
   if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
-  if (const char* e = getenv("JXLHIP_HF_RING")) hf_ring_override = atoi(e);
   if (const char* e = getenv("JXLHIP_HF_STRIDE")) hf_stride_override = atoi(e);
 }
 
@@ -828,11 +826,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
   Mark("hf_start", s_hf, 1);
-  // More workgroups than CUs: the narrow bit window (192 B of LDS per lane instead of 288) lets two of them share a CU, so the
-  // launch is resident in one round and leaves whole CUs to the concurrent pixel stages.
   hf_slots = (hf_slots + 3) & ~3;
-  int hf_ring = npass_t > 256 ? 16 : 32;
-  if (hf_ring_override == 16 || hf_ring_override == 32) hf_ring = hf_ring_override;
+  const int hf_ring = 32;   // words of the per-lane bit window
   lds_hf += (size_t)hf_slots * HfLaneLdsBytes(hf_ring);
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, s_hf);
   Mark("hf_decode", s_hf, 1);
@@ -1014,10 +1009,12 @@ DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
     } else if (S.h_status[(size_t)i * 16]) {
       uint32_t bits = S.h_status[(size_t)i * 16];
       st = DecoderStatus_DecodeError;
-      if (worst == DecoderStatus_Ok)
-        SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
+      if (worst == DecoderStatus_Ok) {
+        const uint32_t* w = S.h_status + (size_t)i * 16;   // [3..7]: last failing section + 1 of lf_ans / lf_finish / hf_decode / alpha_ans / modular
+        SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s; image %d, sections lf %u hf %u alpha %u)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
                bits & kErrUnsupportedHeader ? " unsupported-modular-header" : "", bits & kErrUnsupportedTree ? " unsupported-tree" : "",
-               bits & kErrBlockLayout ? " invalid-varblock-layout" : "", bits & kErrRange ? " value-out-of-range" : "");
+               bits & kErrBlockLayout ? " invalid-varblock-layout" : "", bits & kErrRange ? " value-out-of-range" : "", i, w[3], w[5], w[6]);
+      }
     }
     if (statuses) statuses[i] = st;
     if (st != DecoderStatus_Ok && worst == DecoderStatus_Ok) worst = st;
@@ -1301,6 +1298,20 @@ JXLFILETYPEIO_API DecoderStatus jxlhip_parse_check(const uint8_t* data, size_t s
   } catch (const std::exception& e) {
     SetErr(err, "%s", e.what());
     return DecoderStatus_DecodeError;
+  }
+}
+
+// Host-only: byte sizes of the TOC sections in logical order (LfGlobal, LF groups, HfGlobal, pass groups).  Returns their number.
+JXLFILETYPEIO_API int32_t jxlhip_section_sizes(const uint8_t* data, size_t size, uint32_t* dst, int32_t capacity) {
+  if (!data) return 0;
+  try {
+    ParsedFrame f;
+    ParseFile(data, size, true, f);
+    const int32_t n = (int32_t)f.sec_size.size();
+    for (int32_t i = 0; i < n && i < capacity && dst; i++) dst[i] = f.sec_size[i];
+    return n;
+  } catch (...) {
+    return 0;
   }
 }
 

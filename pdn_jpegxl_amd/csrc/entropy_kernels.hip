@@ -13,6 +13,7 @@
 //    into the same loop), so lanes of a wavefront that own different sections stay convergent;
 //  * `lane_stride` picks the mapping: 64 = one section per wavefront, 1 = one section per lane.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "dev_types.h"
 #include "dev_util.h"
 #include "kernels.h"
@@ -30,7 +31,11 @@ __device__ const uint8_t d_nnz_ctx[64] = {0,   0,   31,  62,  62,  93,  93,  93,
 
 __device__ __forceinline__ int CeilLog2D(uint32_t x) { return x <= 1 ? 0 : 32 - __clz(x - 1); }
 __device__ __forceinline__ int32_t UnpackSigned(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
-__device__ __forceinline__ void SetError(const DevImage& im, uint32_t bits) { atomicOr(im.status, bits); }
+// who: 1 lf_ans, 2 lf_finish, 3 hf_decode, 4 alpha_ans, 5 modular; where: section index (diagnostics: status[2 + who] = where + 1)
+__device__ __forceinline__ void SetError(const DevImage& im, uint32_t bits, int who = 0, int where = 0) {
+  atomicOr(im.status, bits);
+  if (who) im.status[2 + who] = (uint32_t)where + 1;
+}
 
 // Table pointers are typed by address space so that the LDS variants compile to ds_read (not flat_load).
 #define JXL_LDS __attribute__((address_space(3)))
@@ -59,9 +64,10 @@ struct LaneBitsT {
   uint64_t buf;
   int n;
   int skip;
-  __device__ __forceinline__ void Batch() {   // stages words [filled, filled + kBatch)
+  uint32_t pend[kBatch];       // words [filled, filled + kBatch) as requested by the previous top-up, not yet in the ring
+  bool has_pend;
+  __device__ __forceinline__ void Fetch(uint32_t* v) {   // words [filled, filled + kBatch) into registers
     static_assert(kBatch == 4 || kBatch == 8, "one or two 16-byte loads");
-    uint32_t v[kBatch];
     if (filled + kBatch <= nwords) {
       const U4 a = *(const JXL_GLB U4*)(w + filled);
       v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -73,12 +79,29 @@ struct LaneBitsT {
 #pragma unroll
       for (int i = 0; i < kBatch; i++) v[i] = filled + i < nwords ? w[filled + i] : 0u;
     }
+  }
+  __device__ __forceinline__ void Stage(const uint32_t* v) {
 #pragma unroll
     for (int i = 0; i < kBatch; i++) ring[__umul24((filled + i) & (kRing - 1), rs)] = v[i];
     filled += kBatch;
   }
-  __device__ __forceinline__ void TopUp() {
+  __device__ __forceinline__ void Batch() {   // stages words [filled, filled + kBatch), waiting for them
+    uint32_t v[kBatch];
+    Fetch(v);
+    Stage(v);
+  }
+  __device__ __forceinline__ void TopUpSync() {
     while (filled + kBatch <= rd + kRing) Batch();
+  }
+  // Called every kRing / 2 tokens (a token consumes at most 48 bits, so a period consumes at most 3/4 of the window).  The words
+  // requested by the PREVIOUS call go into the ring now - their loads are a whole period old, so this wait is normally free,
+  // whereas load-and-wait on the spot exposed a full L2 / HBM round trip per period (hf_decode took twice as long once a batch held
+  // eight distinct images instead of one cached one) - then the next batch is requested.  Only a burst that drained more than one
+  // batch in a period falls back to waiting.
+  __device__ __forceinline__ void TopUp() {
+    if (has_pend) { Stage(pend); has_pend = false; }
+    while (filled + kBatch <= rd + kRing && filled - rd < (uint32_t)(kRing * 3 / 4)) Batch();
+    if (filled + kBatch <= rd + kRing) { Fetch(pend); has_pend = true; }
   }
   __device__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off, JXL_LDS uint32_t* ring_slot, uint32_t ring_stride) {
     const uintptr_t addr = (uintptr_t)cs + (bit_off >> 3);
@@ -87,9 +110,9 @@ struct LaneBitsT {
     ring = ring_slot; rs = ring_stride;
     const uintptr_t end = ((uintptr_t)cs + cs_size + 3) & ~(uintptr_t)3;
     nwords = end > al ? (uint32_t)((end - al) >> 2) : 0u;
-    rd = 0; filled = 0; buf = 0; n = 0;
+    rd = 0; filled = 0; buf = 0; n = 0; has_pend = false;
     skip = (int)(addr - al) * 8 + (int)(bit_off & 7);
-    TopUp();
+    TopUpSync();
     rd = (uint32_t)skip >> 5;   // whole words before the start are skipped, the rest bit by bit
     Refill();
     const int s2 = skip & 31;
@@ -846,7 +869,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   if (!err && (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
   if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
   im.lf_count[g] = err ? 0u : count;
-  if (err) SetError(im, err);
+  if (err) SetError(im, err, 1, g);
 }
 
 // ------------------------------------------------------------------ LF groups, phase B: one workgroup (4 wavefronts) per LF group
@@ -1047,12 +1070,12 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   typename AS<kLds>::U8 nnz_tab;
   JXL_LDS uint8_t* nzcol;
   JXL_LDS uint32_t* ring_base;
-  JXL_LDS U2* descq;   // per lane: queue of the next kQ varblock descriptors, entry j at descq[(j & (kQ - 1)) * nslots + slot]
+  JXL_LDS U2* descq;   // per lane: queue of the next 2 * kQ varblock descriptors, entry j at descq[(j & (2 * kQ - 1)) * nslots + slot]
   {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     size_t off = 0;
     ring_base = (JXL_LDS uint32_t*)lds; off += (size_t)nslots * kRing * 4;
-    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * kQ * 8;
+    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * 2 * kQ * 8;
     nzcol = lds + off; off += (size_t)nslots * 96;
     if constexpr (kLds) {
       off = StageCode(lds, off, im.acode, tab, threadIdx.x, blockDim.x);
@@ -1086,7 +1109,11 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const JXL_GLB U2* const list = (const JXL_GLB U2*)G(im.blk_list + (size_t)g * 2048);
   const uint32_t nblk = im.blk_count[g];
   JXL_LDS U2* const dq = descq + si;
-  uint32_t bi = 0, dfilled = 0, it = 0;
+  constexpr uint32_t dqmask = 2u * kQ - 1;
+  uint32_t bi = 0, dfilled = 0, it = 0, dpend_n = 0;
+  U2 dpend[kQ];
+#pragma unroll
+  for (int i = 0; i < kQ; i++) dpend[i] = 0u;
   // output: the group's entry list and the per-(block, channel) index (no global load may sit in the token loop - its wait would
   // also wait for the stores - so every pointer is formed up front)
   JXL_GLB uint32_t* const ent = G(im.centries) + (size_t)(g - im.centries_g0) * kGroupEntriesCap;
@@ -1103,14 +1130,30 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   while (!err) {
     if ((it & (kTop - 1)) == 0) {
       b.TopUp();
-      const uint32_t lim = min(nblk, bi + kQ);
-      if (dfilled < lim) {
+      // descriptors the same way: a period starts at most kQ blocks, the queue holds 2 * kQ; what the previous period requested is
+      // queued now, the next kQ are requested
+      if (dpend_n) {
+#pragma unroll
+        for (int i = 0; i < kQ; i++) if ((uint32_t)i < dpend_n) dq[__umul24((dfilled + i) & dqmask, nslots)] = dpend[i];
+        dfilled += dpend_n;
+        dpend_n = 0;
+      }
+      if (dfilled < min(nblk, bi + kQ)) {   // start of the section, or a burst: wait for them
+        const uint32_t lim = min(nblk, bi + kQ);
         U2 v[kQ];
 #pragma unroll
         for (int i = 0; i < kQ; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
 #pragma unroll
-        for (int i = 0; i < kQ; i++) if (dfilled + i < lim) dq[__umul24((dfilled + i) & (kQ - 1), nslots)] = v[i];
+        for (int i = 0; i < kQ; i++) if (dfilled + i < lim) dq[__umul24((dfilled + i) & dqmask, nslots)] = v[i];
         dfilled = lim;
+      }
+      {
+        const uint32_t lim = min(nblk, bi + 2 * kQ);
+        if (dfilled < lim) {
+          dpend_n = min(lim - dfilled, (uint32_t)kQ);
+#pragma unroll
+          for (int i = 0; i < kQ; i++) { dpend[i] = 0u; if ((uint32_t)i < dpend_n) dpend[i] = list[dfilled + i]; }
+        }
       }
     }
     // Fast path: while every lane of the wavefront that is still decoding sits inside a run of coefficient tokens (always the
@@ -1140,7 +1183,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     }
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
-      const U2 d = dq[__umul24(bi & (kQ - 1), nslots)];
+      const U2 d = dq[__umul24(bi & dqmask, nslots)];
       bi++;
       bx = d.x & 31; by = (d.x >> 5) & 31;
       lcx = (d.x >> 15) & 7;
@@ -1205,7 +1248,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const uint64_t used = b.Consumed();
   if (!err && sec_bits + used > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   im.grp_bitpos[g] = err ? ~(uint64_t)0 : sec_bits + used;
-  if (err) SetError(im, err);
+  if (err) SetError(im, err, 3, g);
 }
 
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
@@ -1249,7 +1292,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
     ChanDesc d;
     d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
     *desc = d;
-    SetError(im, err);
+    SetError(im, err, 4, g);
   }
 }
 
@@ -1546,20 +1589,16 @@ void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream
   hipLaunchKernelGGL(hf_blocklist_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 
-size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 4) * 8; }
+size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 2) * 8; }
 
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words,
                     size_t lds_bytes, hipStream_t s) {
   if (nwg <= 0) return;
   const size_t lane_bytes = (size_t)nslots * HfLaneLdsBytes(32);   // tables in global memory: always the wide window
+  (void)ring_words;   // one window size: 32 words (a 16-word variant paid off while the coefficient orders lived in LDS; not any more)
   if (lds_bytes) {
-    if (ring_words == 16) {
-      RaiseLds((const void*)hf_decode_kernel<true, 16>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 16>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
-    } else {
-      RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
-      hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
-    }
+    RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
+    hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
   } else {
     RaiseLds((const void*)hf_decode_kernel<false, 32>, lane_bytes);
     hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride, nslots);

@@ -53,7 +53,10 @@ __device__ __forceinline__ int Mirror(int v, int n) {
 // v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
 // * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
 __device__ __forceinline__ float SrgbOetfT(float v) {
-  return v <= 0.0031308f ? 12.92f * v : 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
+  // both branches are computed and selected (v_cndmask): as a conditional the compiler emitted an exec-mask branch per sample
+  const float lin = 12.92f * v;
+  const float cur = 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
+  return v <= 0.0031308f ? lin : cur;
 }
 __device__ __forceinline__ float PowT(float a, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * e); }   // a > 0
 // Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ.
@@ -69,10 +72,8 @@ __device__ __forceinline__ float EncodeTransferT(int kind, float v, float pq_sca
   }
   return copysignf(r, v);
 }
-__device__ __forceinline__ uint8_t ToU8T(float v) {
-  v *= 255.0f;
-  if (!(v > 0.f)) return 0;
-  if (v >= 255.0f) return 255;
+__device__ __forceinline__ uint8_t ToU8T(float v) {   // round half up, clamped; NaN -> 0 (v_max_f32 returns the other operand)
+  v = fminf(fmaxf(v * 255.0f, 0.f), 255.0f);
   return (uint8_t)(v + 0.5f);
 }
 
@@ -124,28 +125,6 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
 // The common layouts (u8 samples, sRGB or linear transfer) without the branches of the general function: used by the fused filter
 // kernel, whose output phase is a large part of its time.
 __device__ __forceinline__ bool PlainOutput(const DevImage& im) { return im.out_bits == 8 && im.to_srgb <= 1; }
-__device__ __forceinline__ void WritePixelPlain(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
-  const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
-  const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
-  float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
-  float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
-  float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
-  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
-  const size_t o = (size_t)(y - im.band_y0) * im.w + x;
-  if (im.nch_out == 4) {
-    uchar4 px;
-    px.x = ToU8T(r); px.y = ToU8T(g); px.z = ToU8T(bl); px.w = (uint8_t)a;
-    ((uchar4*)im.out)[o] = px;
-  } else {
-    uint8_t* out = im.out + o * im.nch_out;
-    if (im.ncolor == 3) {
-      out[0] = ToU8T(r); out[1] = ToU8T(g); out[2] = ToU8T(bl);
-    } else {
-      out[0] = ToU8T(g);
-      if (im.has_alpha) out[1] = (uint8_t)a;
-    }
-  }
-}
 // Out of line on purpose: inlined four times into the fused filter kernel's unrolled output phase, the general function more than
 // doubled that kernel's code (2.3 k -> 5.8 k instructions) and cost 8 % of its speed on the plain path that never executes it.
 __device__ __noinline__ void WritePixelGeneral(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {
@@ -577,142 +556,207 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
   }
 }
 
-// Gaborish + EPF pass 1 (the only pass of epf_iters == 1) + XYB -> sRGB u8 in one kernel.  Tile = 32 x 32 output pixels:
-// XYB with a 3-pixel halo is staged in LDS, the Gaborish result (2-pixel halo, what the EPF reads) is written to a second LDS
-// tile, the EPF runs from there.  Out-of-frame positions are filled through the mirrored input, which gives the mirrored
-// Gaborish value because the 3x3 kernel is symmetric.  Saves one 24 B/px round trip through HBM and one launch.
-__global__ __launch_bounds__(256) void filter_gab_epf1_kernel(const DevImage* imgs) {
-  constexpr int TW = 32, TH = 32, HI = 3, HG = 2;
-  constexpr int IW = TW + 2 * HI, IH = TH + 2 * HI, GW = TW + 2 * HG, GH = TH + 2 * HG;
-  // LDS: the input tile, overwritten IN PLACE by the Gaborish tile, plus the two difference tiles: 28 KB -> five workgroups per CU
-  // (a separate Gaborish tile made it 34 KB -> four).
-  __shared__ float s_in[3][IH][IW + 1];
-  __shared__ float s_diff[2][GH][GW + 1];
-  float (*t)[IH][IW + 1] = s_in;   // t[c][gy][gx]: Gaborish at input position (gy + 1, gx + 1), stored at input position (gy, gx)
-  const DevImage& im = imgs[blockIdx.y];
-  if (!im.fused_gab_epf1) return;
-  const int w = im.w, h = im.h, wp = im.wp;
-  const int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
-  if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int x0 = tx * TW, y0 = ty * TH;
-  if (y0 + TH <= im.band_y0 || y0 >= im.band_y1) return;
-  const float* in0 = im.stage_in[0][0];
-  const float* in1 = im.stage_in[0][1];
-  const float* in2 = im.stage_in[0][2];
-  // Everything the kernel reads from HBM is requested here, before the first barrier: the output phase's per-pixel operands
-  // (EPF sigma of the pixel's cell, alpha sample) used to be loaded where they are consumed, which parked every wavefront for
-  // a full memory round trip twice more per tile.  Output pixel of iteration `it`: (x0 + lxo, y0 + lyo + 8 * it).
-  const int lxo = threadIdx.x & 31, lyo = threadIdx.x >> 5;
-  const bool plain = PlainOutput(im);
-  float sig[4];
-  uint32_t al[4];
-#pragma unroll
-  for (int it = 0; it < 4; it++) {
-    const int xc = min(x0 + lxo, w - 1), yc = min(y0 + lyo + 8 * it, h - 1);
-    sig[it] = im.inv_sigma[(size_t)(yc >> 3) * im.w8 + (xc >> 3)];
-    al[it] = !im.has_alpha ? 0u : (plain ? (uint32_t)im.alpha[(size_t)yc * w + xc] : LoadAlpha(im, (size_t)yc * w + xc));
-  }
-  if (x0 >= 4 && x0 + TW + 4 <= w && y0 >= HI && y0 + TH + HI <= h) {
-    // interior tile: no mirroring; rows [y0 - 3, y0 + 35) x columns [x0 - 4, x0 + 36) as aligned 16-byte loads
-    constexpr int kQ = (TW + 8) / 4;   // 10 quads per row
-    float4 q[2][3];
-    int qy[2], qx[2];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int e0 = threadIdx.x + it * 256;
-      const int e = e0 < kQ * IH ? e0 : kQ * IH - 1;
-      qy[it] = e / kQ; qx[it] = e % kQ;
-      const size_t g = (size_t)(y0 - HI + qy[it]) * wp + (x0 - 4 + 4 * qx[it]);
-      q[it][0] = *(const float4*)(in0 + g);
-      q[it][1] = *(const float4*)(in1 + g);
-      q[it][2] = *(const float4*)(in2 + g);
-    }
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-      const int lx = 4 * qx[it] - 1;
-#pragma unroll
-      for (int c = 0; c < 3; c++) {
-        if (lx >= 0) s_in[c][qy[it]][lx] = q[it][c].x;
-        s_in[c][qy[it]][lx + 1] = q[it][c].y;
-        s_in[c][qy[it]][lx + 2] = q[it][c].z;
-        if (lx + 3 < IW) s_in[c][qy[it]][lx + 3] = q[it][c].w;
-      }
-    }
+// Gaborish + EPF pass 1 (the only pass of epf_iters == 1) + XYB -> output samples in one kernel, WITHOUT LDS: a group of 16 lanes
+// (one DPP row) owns a strip of 64 columns (16 quads of 4 pixels; the outer quad each side is halo, 56 columns are output) and walks
+// down a segment of rows.  Every lane keeps the rolling windows of its quad in registers - two input rows with their horizontal
+// neighbour sums, three Gaborish rows, three rows of vertical and of horizontal channel-weighted differences - and gets its
+// horizontal neighbours from the lanes beside it by DPP row shifts (v_mov_dpp row_shr / row_shl: one VALU op, no LDS round trip).
+// Per input row a lane issues three 16-byte loads (256 contiguous bytes per group and plane), one row ahead of their use; per
+// output row one 16-byte store.  The LDS-tiled version read ~75 LDS words per pixel (37 % of its LDS cycles bank conflicts) and
+// re-read a 38 x 40 footprint per 32 x 32 tile (1.48x); this one reads 64 / 56 x 70 / 64 = 1.25x and is bound by its VALU work.
+constexpr int kStripOut = 56;    // output columns of a strip (14 quads)
+constexpr int kSegRows = 64;     // output rows of a segment (+ 3 halo rows each side)
+__device__ __forceinline__ float DppFromLeft(float v) {    // value of lane - 1 inside the row of 16 (lane 0: 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float DppFromRight(float v) {   // value of lane + 1 inside the row of 16 (lane 15: 0)
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+}
+__device__ __forceinline__ F4 ShiftFromLeft(F4 v) { return F4{DppFromLeft(v.w), v.x, v.y, v.z}; }      // element x - 1
+__device__ __forceinline__ F4 ShiftFromRight(F4 v) { return F4{v.y, v.z, v.w, DppFromRight(v.x)}; }    // element x + 1
+__device__ __forceinline__ F4 ShiftFromLeft2(F4 v) { return F4{DppFromLeft(v.z), DppFromLeft(v.w), v.x, v.y}; }   // element x - 2
+__device__ __forceinline__ F4 Abs4(F4 v) { return F4{fabsf(v.x), fabsf(v.y), fabsf(v.z), fabsf(v.w)}; }
+
+struct Row3 { F4 c[3]; };
+#define JXL_GLOBAL __attribute__((address_space(1)))
+// Quad (X .. X + 3) of row y of the three planes; rows and columns outside the frame are mirrored like the unfused stages do.
+__device__ __forceinline__ Row3 LoadRow3(const JXL_GLOBAL float* p0, const JXL_GLOBAL float* p1, const JXL_GLOBAL float* p2, int X, int y, int w, int h,
+                                         int wp, bool interior) {
+  const int yy = y < 0 ? -y - 1 : (y >= h ? 2 * h - 1 - y : y);
+  Row3 r;
+  if (interior) {
+    const size_t g = (size_t)yy * wp + X;
+    r.c[0] = *(const JXL_GLOBAL F4*)(p0 + g); r.c[1] = *(const JXL_GLOBAL F4*)(p1 + g); r.c[2] = *(const JXL_GLOBAL F4*)(p2 + g);
   } else {
-    constexpr int kLoadIters = (IW * IH + 255) / 256;
-#pragma unroll
-    for (int it = 0; it < kLoadIters; it++) {
-      const int e0 = threadIdx.x + it * 256;
-      const int e = e0 < IW * IH ? e0 : IW * IH - 1;
-      const int ly = e / IW, lx = e % IW;
-      const size_t g = (size_t)Mirror(y0 - HI + ly, h) * wp + Mirror(x0 - HI + lx, w);
-      const float v0 = in0[g], v1 = in1[g], v2 = in2[g];
-      s_in[0][ly][lx] = v0;
-      s_in[1][ly][lx] = v1;
-      s_in[2][ly][lx] = v2;
-    }
+    const size_t g = (size_t)yy * wp;
+    const int x0 = Mirror(X, w), x1 = Mirror(X + 1, w), x2 = Mirror(X + 2, w), x3 = Mirror(X + 3, w);
+    r.c[0] = F4{p0[g + x0], p0[g + x1], p0[g + x2], p0[g + x3]};
+    r.c[1] = F4{p1[g + x0], p1[g + x1], p1[g + x2], p1[g + x3]};
+    r.c[2] = F4{p2[g + x0], p2[g + x1], p2[g + x2], p2[g + x3]};
   }
-  __syncthreads();
-  // In place, 256 positions (raster order) per round: position (gy, gx) reads inputs (gy..gy+2, gx..gx+2) and is stored at (gy, gx),
-  // which only positions at or before it in raster order read - so a round's stores can only disturb reads of the SAME round
-  // (barrier between its reads and its stores), never a later round's.
-  constexpr int kGabIters = (GW * GH + 255) / 256;
-#pragma unroll 1
-  for (int it = 0; it < kGabIters; it++) {
-    const int e0 = threadIdx.x + it * 256;
-    const int e = min(e0, GW * GH - 1);
-    const int gy = e / GW, gx = e % GW;
-    const int cy = gy + 1, cx = gx + 1;   // same position in the input tile (halo 3 vs 2)
-    float gab[3];
+  return r;
+}
+// XYB -> sRGB-encoded u8 (the plain output layouts)
+__device__ __forceinline__ uint32_t PixelToRgba8(const DevImage& im, float X, float Y, float B, uint32_t a) {
+  const float gr = Y + X - im.opsin_bias_cbrt[0], gg = Y - X - im.opsin_bias_cbrt[1], gb = B - im.opsin_bias_cbrt[2];
+  const float mr = gr * gr * gr + im.opsin_bias[0], mg = gg * gg * gg + im.opsin_bias[1], mb = gb * gb * gb + im.opsin_bias[2];
+  float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
+  float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
+  float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
+  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
+  return (uint32_t)ToU8T(r) | (uint32_t)ToU8T(g) << 8 | (uint32_t)ToU8T(bl) << 16 | a << 24;
+}
+
+// Rolling windows of one lane, as four slots each, indexed by (row & 3) with COMPILE-TIME phases (the row loop is unrolled by four):
+// no register moves to shift a window.  in / s: input rows and their horizontal neighbour sums; g: Gaborish rows; dv / dh: vertical /
+// horizontal channel-weighted differences of Gaborish rows; hd: dv[x-1] + dv[x+1].
+struct StreamState {
+  Row3 in[4], s[4], g[4];
+  F4 dv[4], dh[4], hd[4];
+};
+struct StreamConst {
+  const JXL_GLOBAL float *in0, *in1, *in2, *inv_sigma;
+  const JXL_GLOBAL uint8_t* alpha;
+  float gw0[3], gw1[3], gw2[3], cs[3], bsm;
+  int X, w, h, wp, w8, y0, y1, r_end, cellx, xa;
+  bool interior, stores, full_quad, plain, xb0, xb3;
+};
+
+// One input row r (phase P = (r - first row) & 3): Gaborish row r - 1, differences, and the output row r - 3.
+template <int P>
+__device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst& k, StreamState& st, Row3& next, int r) {
+  constexpr int s0 = P, s1 = (P + 1) & 3, s2 = (P + 2) & 3, s3 = (P + 3) & 3;   // slots of rows r (= r - 4), r - 3, r - 2, r - 1
+  const Row3 cur = next;
+  next = LoadRow3(k.in0, k.in1, k.in2, k.X, min(r + 1, k.r_end - 1), k.w, k.h, k.wp, k.interior);
+  // operands of the output row y = r - 3, requested a whole row of arithmetic ahead of their use
+  const int y = r - 3;
+  const int yc = min(max(y, 0), k.h - 1);
+  const float is = k.inv_sigma[(size_t)(yc >> 3) * k.w8 + k.cellx];
+  uint32_t al = 0xFFFFFFFFu;
+  if (im.has_alpha && k.plain) {
+    const JXL_GLOBAL uint8_t* ap = k.alpha + (size_t)yc * k.w + k.xa;
+    al = (uint32_t)ap[0] | (uint32_t)ap[1] << 8 | (uint32_t)ap[2] << 16 | (uint32_t)ap[3] << 24;
+  }
+  const F4 zero = {0.f, 0.f, 0.f, 0.f};
+  F4 dhn = zero, dvn = zero;
+  st.in[s0] = cur;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    st.s[s0].c[c] = ShiftFromLeft(cur.c[c]) + ShiftFromRight(cur.c[c]);
+    // Gaborish of row r - 1 from input rows r - 2, r - 1, r
+    const F4 gn = st.in[s3].c[c] * k.gw0[c] + ((st.in[s2].c[c] + cur.c[c]) + st.s[s3].c[c]) * k.gw1[c] + (st.s[s2].c[c] + st.s[s0].c[c]) * k.gw2[c];
+    dhn += Abs4(gn - ShiftFromRight(gn)) * k.cs[c];      // dh[r-1][x] = sum_c scale_c |gab[x] - gab[x + 1]|
+    dvn += Abs4(st.g[s2].c[c] - gn) * k.cs[c];            // dv[r-2][x] = sum_c scale_c |gab[r-2] - gab[r-1]|
+    st.g[s3].c[c] = gn;
+  }
+  // now: g[s0] = gab[r-4], g[s1] = gab[r-3], g[s2] = gab[r-2]; dv[s3] = dv[r-5], dv[s0] = dv[r-4], dv[s1] = dv[r-3]; dh[s0..s2] = dh[r-4..r-2]
+  const F4 dv0 = st.dv[s3], dv1 = st.dv[s0], dv2 = st.dv[s1];
+  const F4 hd2 = ShiftFromLeft(dv2) + ShiftFromRight(dv2);    // dv[y][x-1] + dv[y][x+1]
+  const F4 hd1 = st.hd[s0];
+  if (y >= k.y0 && y < k.y1) {   // uniform over the wavefront except for its groups in a shorter last segment
+    // EPF pass 1 of row y: neighbours up / left / right / down, SAD over the plus-shaped support
+    const F4 dh0 = st.dh[s0], dh1 = st.dh[s1], dh2 = st.dh[s2];
+    const F4 a = dv1 + dv2;
+    const F4 sad_u = a + dv0 + hd1, sad_d = a + dvn + hd2;
+    const F4 vh = dh0 + dh1 + dh2;
+    const F4 sad_r = vh + (ShiftFromLeft(dh1) + ShiftFromRight(dh1));
+    const F4 sad_l = ShiftFromLeft(vh) + (ShiftFromLeft2(dh1) + dh1);
+    const bool yb = ((y & 7) == 0) || ((y & 7) == 7);
+    const float inv_in = is * (yb ? k.bsm : 1.0f), inv_b = is * k.bsm;
+    const F4 inv = {k.xb0 ? inv_b : inv_in, inv_in, inv_in, k.xb3 ? inv_b : inv_in};
+    const bool skip = is < -3.90524291751269967465540850526868f;
+    F4 wu, wl, wr, wd, iw;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      wu[j] = fmaxf(0.f, 1.0f + sad_u[j] * inv[j]); wl[j] = fmaxf(0.f, 1.0f + sad_l[j] * inv[j]);
+      wr[j] = fmaxf(0.f, 1.0f + sad_r[j] * inv[j]); wd[j] = fmaxf(0.f, 1.0f + sad_d[j] * inv[j]);
+      iw[j] = __builtin_amdgcn_rcpf(1.0f + wu[j] + wl[j] + wr[j] + wd[j]);
+    }
+    F4 o[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-      gab[c] = s_in[c][cy][cx] * im.gab_w[c][0] +
-               (s_in[c][cy - 1][cx] + s_in[c][cy + 1][cx] + s_in[c][cy][cx - 1] + s_in[c][cy][cx + 1]) * im.gab_w[c][1] +
-               (s_in[c][cy - 1][cx - 1] + s_in[c][cy - 1][cx + 1] + s_in[c][cy + 1][cx - 1] + s_in[c][cy + 1][cx + 1]) * im.gab_w[c][2];
+      const F4 g1 = st.g[s1].c[c];
+      const F4 f = (g1 + wu * st.g[s0].c[c] + wl * ShiftFromLeft(g1) + wr * ShiftFromRight(g1) + wd * st.g[s2].c[c]) * iw;
+      o[c] = skip ? g1 : f;
     }
-    __syncthreads();
-    if (e0 < GW * GH) { t[0][gy][gx] = gab[0]; t[1][gy][gx] = gab[1]; t[2][gy][gx] = gab[2]; }
+    if (k.stores) {
+      if (k.plain && im.nch_out == 4 && k.full_quad) {
+        typedef unsigned __attribute__((ext_vector_type(4))) U4v;
+        U4v px;
+        px.x = PixelToRgba8(im, o[0].x, o[1].x, o[2].x, al & 0xFF);
+        px.y = PixelToRgba8(im, o[0].y, o[1].y, o[2].y, (al >> 8) & 0xFF);
+        px.z = PixelToRgba8(im, o[0].z, o[1].z, o[2].z, (al >> 16) & 0xFF);
+        px.w = PixelToRgba8(im, o[0].w, o[1].w, o[2].w, al >> 24);
+        *(JXL_GLOBAL U4v*)((JXL_GLOBAL uint8_t*)im.out + ((size_t)(y - im.band_y0) * k.w + k.X) * 4) = px;
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+          if (k.X + j >= k.w) break;
+          const uint32_t aj = !im.has_alpha ? 0u : LoadAlpha(im, (size_t)y * k.w + k.X + j);   // (the packed quad `al` is only valid for whole quads)
+          const float ox = j == 0 ? o[0].x : (j == 1 ? o[0].y : (j == 2 ? o[0].z : o[0].w));
+          const float oy = j == 0 ? o[1].x : (j == 1 ? o[1].y : (j == 2 ? o[1].z : o[1].w));
+          const float ob = j == 0 ? o[2].x : (j == 1 ? o[2].y : (j == 2 ? o[2].z : o[2].w));
+          WritePixelGeneral(im, k.X + j, y, ox, oy, ob, aj);
+        }
+      }
+    }
   }
-  __syncthreads();
-  // Channel-weighted absolute differences between horizontal / vertical neighbours, once per pair: the SAD of a pixel against its
-  // neighbour over the plus-shaped support is then five reads instead of thirty.
-  float (*dh)[GW + 1] = s_diff[0];   // dh[y][x] = sum_c scale_c |t_c[y][x] - t_c[y][x + 1]|
-  float (*dv)[GW + 1] = s_diff[1];   // dv[y][x] = ... |t_c[y][x] - t_c[y + 1][x]|
-  const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
-  for (int e = threadIdx.x; e < GW * GH; e += 256) {
-    const int gy = e / GW, gx = e % GW;
-    if (gx + 1 < GW)
-      dh[gy][gx] = fabsf(t[0][gy][gx] - t[0][gy][gx + 1]) * cs0 + fabsf(t[1][gy][gx] - t[1][gy][gx + 1]) * cs1 + fabsf(t[2][gy][gx] - t[2][gy][gx + 1]) * cs2;
-    if (gy + 1 < GH)
-      dv[gy][gx] = fabsf(t[0][gy][gx] - t[0][gy + 1][gx]) * cs0 + fabsf(t[1][gy][gx] - t[1][gy + 1][gx]) * cs1 + fabsf(t[2][gy][gx] - t[2][gy + 1][gx]) * cs2;
-  }
-  __syncthreads();
+  st.dv[s2] = dvn;   // dv[r-2]
+  st.dh[s3] = dhn;   // dh[r-1]
+  st.hd[s1] = hd2;   // of dv[r-3]: next row's hd1
+}
+
+__global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.fused_gab_epf1) return;
+  StreamConst k;
+  k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8;
+  const int strips = (k.w + kStripOut - 1) / kStripOut;
+  const int band_rows = im.band_y1 - im.band_y0;
+  const int segs = (band_rows + kSegRows - 1) / kSegRows;
+  if ((int)blockIdx.x * 16 >= strips * segs) return;   // whole workgroup past the end
+  // every lane stays in the loop (DPP reads neighbouring lanes); groups past the end repeat the last task and store nothing
+  const int gidx = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool task = gidx < strips * segs;
+  const int gi = task ? gidx : strips * segs - 1;
+  const int strip = gi % strips, seg = gi / strips;
+  const int q = threadIdx.x & 15;
+  k.X = strip * kStripOut - 4 + 4 * q;           // first column of this lane's quad
+  k.y0 = im.band_y0 + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, im.band_y1);
+  k.r_end = k.y1 + 3;
+  k.interior = k.X >= 0 && k.X + 3 < k.w;
+  k.stores = task && q >= 1 && q <= 14 && k.X < k.w;
+  k.full_quad = k.X + 3 < k.w;
+  k.in0 = (const JXL_GLOBAL float*)im.stage_in[0][0];
+  k.in1 = (const JXL_GLOBAL float*)im.stage_in[0][1];
+  k.in2 = (const JXL_GLOBAL float*)im.stage_in[0][2];
+  k.inv_sigma = (const JXL_GLOBAL float*)im.inv_sigma;
+  k.alpha = (const JXL_GLOBAL uint8_t*)im.alpha;
+  k.plain = PlainOutput(im);
 #pragma unroll
-  for (int it = 0; it < 4; it++) {
-    const int ly = lyo + 8 * it, lx = lxo;
-    const int x = x0 + lx, y = y0 + ly;
-    if (x >= w || y < im.band_y0 || y >= im.band_y1) continue;
-    const int cy = ly + HG, cx = lx + HG;
-    const float is = sig[it];
-    float o0 = t[0][cy][cx], o1 = t[1][cy][cx], o2 = t[2][cy][cx];
-    if (!(is < -3.90524291751269967465540850526868f)) {
-      const bool border = ((x & 7) == 0) || ((x & 7) == 7) || ((y & 7) == 0) || ((y & 7) == 7);
-      const float inv = is * (border ? im.epf_border_sad_mul : 1.0f);
-      // SAD against the neighbour above / left / right / below, summed over the support {centre, up, down, left, right}
-      const float sad_u = dv[cy - 1][cx] + dv[cy - 2][cx] + dv[cy][cx] + dv[cy - 1][cx - 1] + dv[cy - 1][cx + 1];
-      const float sad_l = dh[cy][cx - 1] + dh[cy - 1][cx - 1] + dh[cy + 1][cx - 1] + dh[cy][cx - 2] + dh[cy][cx];
-      const float sad_r = dh[cy][cx] + dh[cy - 1][cx] + dh[cy + 1][cx] + dh[cy][cx - 1] + dh[cy][cx + 1];
-      const float sad_d = dv[cy][cx] + dv[cy - 1][cx] + dv[cy + 1][cx] + dv[cy][cx - 1] + dv[cy][cx + 1];
-      const float w_u = fmaxf(0.0f, 1.0f + sad_u * inv), w_l = fmaxf(0.0f, 1.0f + sad_l * inv);
-      const float w_r = fmaxf(0.0f, 1.0f + sad_r * inv), w_d = fmaxf(0.0f, 1.0f + sad_d * inv);
-      const float iw = 1.0f / (1.0f + w_u + w_l + w_r + w_d);
-      o0 = (o0 + w_u * t[0][cy - 1][cx] + w_l * t[0][cy][cx - 1] + w_r * t[0][cy][cx + 1] + w_d * t[0][cy + 1][cx]) * iw;
-      o1 = (o1 + w_u * t[1][cy - 1][cx] + w_l * t[1][cy][cx - 1] + w_r * t[1][cy][cx + 1] + w_d * t[1][cy + 1][cx]) * iw;
-      o2 = (o2 + w_u * t[2][cy - 1][cx] + w_l * t[2][cy][cx - 1] + w_r * t[2][cy][cx + 1] + w_d * t[2][cy + 1][cx]) * iw;
-    }
-    if (plain) WritePixelPlain(im, x, y, o0, o1, o2, al[it]);
-    else WritePixelGeneral(im, x, y, o0, o1, o2, al[it]);
+  for (int c = 0; c < 3; c++) { k.gw0[c] = im.gab_w[c][0]; k.gw1[c] = im.gab_w[c][1]; k.gw2[c] = im.gab_w[c][2]; k.cs[c] = im.epf_channel_scale[c]; }
+  k.bsm = im.epf_border_sad_mul;
+  // block-border columns of the quad: strips start on a multiple of 8, so X = 4 (q - 1) mod 8
+  k.xb0 = (q & 1) != 0; k.xb3 = (q & 1) == 0;     // component 0 is column 0 of a block / component 3 is column 7
+  k.cellx = min(max(k.X, 0), k.w - 1) >> 3;
+  k.xa = min(max(k.X, 0), max(k.w - 4, 0));       // alpha quad (clamped: halo lanes and partial quads never use it)
+  StreamState st;
+  const F4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { st.in[i].c[c] = zero; st.s[i].c[c] = zero; st.g[i].c[c] = zero; }
+    st.dv[i] = zero; st.dh[i] = zero; st.hd[i] = zero;
+  }
+  const int r0 = k.y0 - 3;
+  Row3 next = LoadRow3(k.in0, k.in1, k.in2, k.X, r0, k.w, k.h, k.wp, k.interior);
+  // four rows per trip, unconditionally (rows past the end recompute the last input row and store nothing: y >= y1): with
+  // conditional phases the compiler must keep every slot of every window alive across the back edge
+  for (int r = r0; r < k.r_end; r += 4) {
+    StreamRow<0>(im, k, st, next, r);
+    StreamRow<1>(im, k, st, next, r + 1);
+    StreamRow<2>(im, k, st, next, r + 2);
+    StreamRow<3>(im, k, st, next, r + 3);
   }
 }
 
@@ -740,7 +784,8 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
-    hipLaunchKernelGGL(filter_gab_epf1_kernel, dim3(((max_w + 31) / 32) * ((max_h + 31) / 32), nimg), dim3(256), 0, s, imgs);
+    const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + kSegRows - 1) / kSegRows);   // one group of 16 lanes per (strip, segment)
+    hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + 15) / 16, nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);

@@ -75,3 +75,57 @@ def decode_frame_sharded(dec, data, dst=0):
     elif info.bytes_per_sample == 4:
         img = img.view(torch.float32)
     return img.reshape(info.height, info.width, info.num_channels)
+
+
+class BandDecoder:
+    """One rank's share of a band-sharded frame, set up once and stepped many times (bench.py --workload 16k-bands): the file goes
+    to HBM once, the band and gather buffers are allocated once, and a step is decode(band) + one all_gather.
+    gather_device "cuda" = RCCL over xGMI; "cpu" = gloo (one-GPU rehearsals and the CPU tests)."""
+
+    def __init__(self, dec, data, rank, world, gather_device="cuda", device="cuda"):
+        from . import api
+        self.dec, self.data, self.rank, self.world = dec, data, rank, world
+        self.info = info = api.peek(data)
+        n_rows = (info.height + 255) // 256
+        self.spans = [band_rows(n_rows, r, world) for r in range(world)]
+        self.row_bytes = info.width * info.num_channels * info.bytes_per_sample
+        self.rows_per_rank = [min(b * 256, info.height) - min(a * 256, info.height) for a, b in self.spans]
+        self.r0, self.r1 = self.spans[rank]
+        self.rows = self.rows_per_rank[rank]
+        self.max_bytes = max(1, max(self.rows_per_rank) * self.row_bytes)
+        self.src = torch.zeros(len(data) + 64, dtype=torch.uint8, device=device)
+        self.src[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(device)
+        self.band = torch.zeros(self.max_bytes, dtype=torch.uint8, device=device)   # padded to the tallest band: equal all_gather shares
+        self.gather_device = gather_device
+        self.gathered = torch.empty(world * self.max_bytes, dtype=torch.uint8, device=gather_device) if world > 1 else None
+
+    def decode(self):
+        if self.r1 <= self.r0:
+            return
+        self.dec.set_option("band_first_row", self.r0)
+        self.dec.set_option("band_rows", self.r1 - self.r0)
+        try:
+            st = self.dec.decode_batch([self.data], [self.band.data_ptr()], [self.src.data_ptr()], synchronize=True)
+        finally:
+            self.dec.set_option("band_rows", 0)
+        if st[0] != 0:
+            raise RuntimeError("band decode failed with status %d" % st[0])
+
+    def gather(self):
+        if self.world == 1:
+            return
+        share = self.band if self.gather_device == self.band.device.type else self.band.to(self.gather_device)
+        dist.all_gather_into_tensor(self.gathered, share)
+
+    def step(self):
+        self.decode()
+        self.gather()
+
+    def image(self):
+        """The whole frame as an (H, W, C) uint8 tensor (u8 streams) assembled from the gathered bands; call after step()."""
+        info = self.info
+        if self.world == 1:
+            flat = self.band[: self.rows * self.row_bytes]
+        else:
+            flat = torch.cat([self.gathered[r * self.max_bytes: r * self.max_bytes + n * self.row_bytes] for r, n in enumerate(self.rows_per_rank)])
+        return flat.reshape(info.height, info.width * info.num_channels * info.bytes_per_sample)

@@ -29,6 +29,11 @@ CASES = {
 }
 
 
+# The inputs of bench.py (BASELINE.json configs[1]): eight DISTINCT 3840x2160 RGBA8 images, distance 1.0, default heuristics of the
+# oracle's encoder (variable transform sizes).  Written by `make_golden.py --bench` into bench_index.json.
+BENCH_CASES = {"synth_3840x2160_seed%d_d1" % seed: dict(size=(3840, 2160), seed=seed, nch=4, enc=dict(distance=1.0)) for seed in range(2, 10)}
+
+
 def source(case):
     w, h = case["size"]
     bits = case["enc"].get("bits", 8)
@@ -38,19 +43,20 @@ def source(case):
 
 
 def main():
+    bench = "--bench" in sys.argv
     index = {}
-    for name, case in CASES.items():
+    for name, case in (BENCH_CASES if bench else CASES).items():
         src = np.ascontiguousarray(source(case))
         data = O.encode(src, num_threads=1, **case["enc"])
-        dec = O.decode(data, num_threads=1)
+        dec = O.decode(data, num_threads=8 if bench else 1)
         with open(os.path.join(HERE, name + ".jxl"), "wb") as f:
             f.write(data)
         index[name] = dict(size=case["size"], nch=case["nch"], seed=case["seed"], enc=case["enc"], jxl_bytes=len(data),
                            jxl_sha256=hashlib.sha256(data).hexdigest(), pixels_sha256=hashlib.sha256(dec.pixels.tobytes()).hexdigest(),
                            source_sha256=hashlib.sha256(src.tobytes()).hexdigest())
-    with open(os.path.join(HERE, "index.json"), "w") as f:
+    with open(os.path.join(HERE, "bench_index.json" if bench else "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
-    print(json.dumps(index, indent=1))
+    print(json.dumps(index, indent=1) if not bench else "%d bench fixtures written" % len(index))
 
 
 if __name__ == "__main__":

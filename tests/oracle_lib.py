@@ -19,6 +19,28 @@ def build():
     subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(_ROOT, "oracle")])
 
 
+def build_native():
+    """-O3 -march=native build for the machine this runs on (bench.py's cpu_baseline leg; the default build is portable because it
+    travels from the build container to the GPU box).  Returns the path of the library."""
+    # keyed by the CPU's feature flags: a build made elsewhere (e.g. in the container the repo was snapshotted from) is never reused
+    import hashlib
+    try:
+        flags = [l for l in open("/proc/cpuinfo") if l.startswith("flags")][0]
+    except Exception:
+        flags = "unknown"
+    out = os.path.join("_build", "native-" + hashlib.sha1(flags.encode()).hexdigest()[:10])
+    subprocess.check_call(["make", "-s", "-j16", "-C", os.path.join(_ROOT, "oracle"), "BUILD=" + out,
+                           "CXXFLAGS=-O3 -march=native -std=c++17 -fPIC -pthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return os.path.join(_ROOT, "oracle", out, "libjxo.so")
+
+
+def use(path):
+    """Binds a different build of the oracle library (before or after the first call)."""
+    global _lib, _SO
+    _SO = path
+    _lib = None
+
+
 _lib = None
 
 

@@ -453,7 +453,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.lf_desc = ws.Take((size_t)f.nlf * 8 * sizeof(ChanDesc));
     l.lf_count = ws.Take((size_t)f.nlf * 4);
     l.alpha_desc = ws.Take((size_t)f.ng * sizeof(ChanDesc));
-    l.blk_list = ws.Take((size_t)f.ng * 2048 * 4);
+    l.blk_list = ws.Take((size_t)f.ng * 1024 * 4);
     l.blk_count = ws.Take((size_t)f.ng * 4);
     l.bitpos = ws.Take((size_t)f.ng * 8);
     l.tile_list = ws.Take(tiles * 4);
@@ -519,9 +519,21 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (need > 4 && lane_stride <= 8) hf_waves = std::min(8, need);
   }
   const int per_wg = hf_waves * (64 / lane_stride);
+  // Sections per workgroup, per image: the HF kernel's LDS is the image's code tables (30 .. 60 KB: they double with the alias-table
+  // width) plus 288 B per lane, and a launch has ONE LDS size.  Sized by the batch-wide maximum, a single image with wide tables
+  // pushed every workgroup from two per CU to one (hf_decode 30 -> 58 ms at batch 384); instead every image gets as many lanes per
+  // workgroup as fit beside ITS tables in half a CU's LDS (whole wavefronts; images with wide tables use more, smaller workgroups).
+  auto hf_table_bytes = [](const ParsedFrame& f) { return 8 + 8 * f.acode.alias.size() + 4 * f.acode.cfg.size() + f.acode.ctx_map.size() + 64 + 32; };
+  const size_t kHfLdsTarget = 80 * 1024;
+  auto hf_per_wg = [&](const ParsedFrame& f) {
+    const int per_wave = 64 / lane_stride;
+    const size_t tab = hf_table_bytes(f);
+    int lanes = tab + HfLaneLdsBytes(32) * per_wave <= kHfLdsTarget ? (int)((kHfLdsTarget - tab) / HfLaneLdsBytes(32)) / per_wave * per_wave : per_wave;
+    return std::max(per_wave, std::min(per_wg, lanes));
+  };
   int n_pass_wg = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_pass_wg += ((int)frames[i].ng + per_wg - 1) / per_wg;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_pass_wg += ((int)frames[i].ng + hf_per_wg(frames[i]) - 1) / hf_per_wg(frames[i]);
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
   // Lane mapping of the alpha phase-A kernel (one wavefront per workgroup, sections of one image per wavefront): spread the
@@ -559,8 +571,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   memset(h_blob, 0, blob.off);
   imgs.assign(n, DevImage());
   status_off.assign(n, 0);
-  size_t lds_hf = 0, lds_lf = 0, lds_alpha = 0;
-  int hf_slots = 0;   // lanes the HF kernel's LDS arrays are laid out for: the largest section count of a workgroup
+  size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
   bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
@@ -783,7 +794,6 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-    lds_hf = std::max(lds_hf, code_lds(f.acode) + 64 + 32);   // tables; the per-lane part is added below
     lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = lds_lf;
     max_groups = std::max<int>(max_groups, (int)f.ng);
@@ -795,15 +805,21 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (uint32_t g = l0; g < l1; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, l1 - g), 0};
     }
     const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
-    for (uint32_t g = hg0; g < hg1; g += per_wg) {
-      pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_wg, hg1 - g), 0};
-      hf_slots = std::max<int>(hf_slots, (int)std::min<uint32_t>(per_wg, hg1 - g));
+    const uint32_t pw = (uint32_t)hf_per_wg(f);
+    for (uint32_t g = hg0; g < hg1; g += pw) {
+      const uint32_t cnt = std::min<uint32_t>(pw, hg1 - g);
+      pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)cnt, 0};
+      const size_t lanes = (size_t)((cnt + 3) & ~3u) * HfLaneLdsBytes(32);   // the kernel lays its per-lane arrays out for the task's lanes
+      lds_hf = std::max(lds_hf, hf_table_bytes(f) + lanes);
+      lds_hf_lanes = std::max(lds_hf_lanes, lanes);
     }
     const uint32_t ag0 = (uint32_t)(d.band_y0 / kGroupDim) * f.xg, ag1 = (uint32_t)((d.band_y1 + kGroupDim - 1) / kGroupDim) * f.xg;
     if (d.has_alpha)
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
         alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, ag1 - g), 0};
   }
+  const int hf_ring = 32;   // words of the per-lane bit window
+  const size_t kLdsMax = 150 * 1024;
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
   d_imgs = (DevImage*)(d_blob + off_imgs);
   // ---- 4. enqueue: LF chain on s_lf, everything that needs the block layout on the main stream
@@ -813,7 +829,6 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
-  const size_t kLdsMax = 150 * 1024;
   LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
   Mark("lf_ans", s_lf, 0);
   LaunchLfFinish(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, s_lf);
@@ -826,10 +841,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
   Mark("hf_start", s_hf, 1);
-  hf_slots = (hf_slots + 3) & ~3;
-  const int hf_ring = 32;   // words of the per-lane bit window
-  lds_hf += (size_t)hf_slots * HfLaneLdsBytes(hf_ring);
-  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_slots, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, s_hf);
+  LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, lds_hf_lanes, s_hf);
   Mark("hf_decode", s_hf, 1);
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages

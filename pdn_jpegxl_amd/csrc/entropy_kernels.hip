@@ -1000,8 +1000,7 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
 // Pre-pass (fully parallel, one wavefront per group): the varblocks of the group in decode order, each with the block
 // context of its three channels, so that the serial token loop below never waits on cellinfo / raw-quant / context-map
 // loads: it streams 8-byte descriptors, fetched one block ahead.
-//   word0 = bx | by << 5 | strategy << 10 | log2cx << 15 | log2cy << 18 | order bucket << 21
-//   word1 = block context of Y | X << 8 | B << 16
+//   one word: bx | by << 5 | log2cx << 10 | log2cy << 13 | block context of Y << 16 | X << 21 | B << 26   (at most 16 block contexts)
 __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
   const int g = blockIdx.x;
@@ -1010,7 +1009,7 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
   const int gx = g % im.xg, gy = g / im.xg;
   const int bx0 = gx * kGroupBlocks, by0 = gy * kGroupBlocks;
   const int bw = min(kGroupBlocks, im.w8 - bx0), bh = min(kGroupBlocks, im.h8 - by0);
-  U2* list = (U2*)(im.blk_list + (size_t)g * 2048);
+  uint32_t* list = im.blk_list + (size_t)g * 1024;
   const int n_qf = im.n_qf;
   uint32_t total = 0;
   for (int it = 0; it < 16; it++) {
@@ -1034,12 +1033,9 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
         const uint32_t cprime = c < 2 ? (c ^ 1) : 2;
-        ctxs |= (uint32_t)im.block_ctx_map[(cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx] << (8 * ci);
+        ctxs |= ((uint32_t)im.block_ctx_map[(cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx] & 31u) << (5 * ci);
       }
-      U2 d;
-      d.x = (uint32_t)bx | (uint32_t)by << 5 | s << 10 | lcx << 15 | lcy << 18 | ord << 21;
-      d.y = ctxs;
-      list[pos] = d;
+      list[pos] = (uint32_t)bx | (uint32_t)by << 5 | lcx << 10 | lcy << 13 | ctxs << 16;
     }
     total += (uint32_t)__popcll(m);
   }
@@ -1056,9 +1052,9 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
 // kRing: words of the per-lane bit window.  32 (top-up every 16 tokens, 8 queued descriptors: 288 B of LDS per lane) is the
 // faster loop for one frame; 16 (top-up every 8 tokens, 4 descriptors: 192 B per lane) lets more workgroups share a CU, which is
 // what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
-// (>= the largest task.count of the launch).
+// (the task's section count rounded up to four: every workgroup uses what ITS image's tables leave of the launch's LDS).
 template <bool kLds, int kRing>
-__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int nslots) {
+__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
   typedef LaneBitsT<kRing, kRing / 4> Bits;
@@ -1066,16 +1062,17 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   const int per_wave = 64 / lane_stride;
+  const int nslots = (task.count + 3) & ~3;
   CodeTab<kLds> tab;
   typename AS<kLds>::U8 nnz_tab;
   JXL_LDS uint8_t* nzcol;
   JXL_LDS uint32_t* ring_base;
-  JXL_LDS U2* descq;   // per lane: queue of the next 2 * kQ varblock descriptors, entry j at descq[(j & (2 * kQ - 1)) * nslots + slot]
+  JXL_LDS uint32_t* descq;   // per lane: queue of the next 2 * kQ varblock descriptors, entry j at descq[(j & (2 * kQ - 1)) * nslots + slot]
   {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     size_t off = 0;
     ring_base = (JXL_LDS uint32_t*)lds; off += (size_t)nslots * kRing * 4;
-    descq = (JXL_LDS U2*)(lds + off); off += (size_t)nslots * 2 * kQ * 8;
+    descq = (JXL_LDS uint32_t*)(lds + off); off += (size_t)nslots * 2 * kQ * 4;
     nzcol = lds + off; off += (size_t)nslots * 96;
     if constexpr (kLds) {
       off = StageCode(lds, off, im.acode, tab, threadIdx.x, blockDim.x);
@@ -1106,12 +1103,12 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   uint32_t state = b.Read(32);
   const int gx = g % im.xg, gy = g / im.xg;
   // block descriptors: staged through a small LDS queue that is topped up together with the bit window
-  const JXL_GLB U2* const list = (const JXL_GLB U2*)G(im.blk_list + (size_t)g * 2048);
+  const JXL_GLB uint32_t* const list = G(im.blk_list + (size_t)g * 1024);
   const uint32_t nblk = im.blk_count[g];
-  JXL_LDS U2* const dq = descq + si;
+  JXL_LDS uint32_t* const dq = descq + si;
   constexpr uint32_t dqmask = 2u * kQ - 1;
   uint32_t bi = 0, dfilled = 0, it = 0, dpend_n = 0;
-  U2 dpend[kQ];
+  uint32_t dpend[kQ];
 #pragma unroll
   for (int i = 0; i < kQ; i++) dpend[i] = 0u;
   // output: the group's entry list and the per-(block, channel) index (no global load may sit in the token loop - its wait would
@@ -1140,7 +1137,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       }
       if (dfilled < min(nblk, bi + kQ)) {   // start of the section, or a burst: wait for them
         const uint32_t lim = min(nblk, bi + kQ);
-        U2 v[kQ];
+        uint32_t v[kQ];
 #pragma unroll
         for (int i = 0; i < kQ; i++) { v[i] = 0u; if (dfilled + i < lim) v[i] = list[dfilled + i]; }
 #pragma unroll
@@ -1183,12 +1180,12 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     }
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
-      const U2 d = dq[__umul24(bi & dqmask, nslots)];
+      const uint32_t d = dq[__umul24(bi & dqmask, nslots)];
       bi++;
-      bx = d.x & 31; by = (d.x >> 5) & 31;
-      lcx = (d.x >> 15) & 7;
-      const uint32_t lcy = (d.x >> 18) & 7;
-      ctxs = d.y;
+      bx = d & 31; by = (d >> 5) & 31;
+      lcx = (d >> 10) & 7;
+      const uint32_t lcy = (d >> 13) & 7;
+      ctxs = d >> 16;
       log2c = lcx + lcy; covered = 1u << log2c; size = covered << 6;
       cell = __umul24(by, w8) + bx;
       ci = 0;
@@ -1201,7 +1198,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)cc[0];
       else if (by == 0) predicted = cc[__umul24(bx - 1, nslots)];
       else predicted = ((uint32_t)cc[__umul24(bx, nslots)] + cc[__umul24(bx - 1, nslots)] + 1) >> 1;
-      const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
+      const uint32_t block_ctx = (ctxs >> (5 * ci)) & 31;
       uint32_t nzc = predicted >= 64 ? 64 : predicted;
       nzc = nzc < 8 ? nzc : 4 + nzc / 2;
       ctx = ctx_offset + nzc * nbc + block_ctx;
@@ -1223,7 +1220,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       rec.x = epos; rec.y = nzeros;
       cblk[(size_t)c * ncells + cell] = rec;
       if (nzeros) {
-        const uint32_t block_ctx = (ctxs >> (8 * ci)) & 0xFF;
+        const uint32_t block_ctx = (ctxs >> (5 * ci)) & 31;
         histo = ctx_offset + nbc * 37 + 458 * block_ctx;
         prev = nzeros > size / 16 ? 0 : 1;
         k = covered;
@@ -1589,19 +1586,18 @@ void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream
   hipLaunchKernelGGL(hf_blocklist_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 
-size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 2) * 8; }
+size_t HfLaneLdsBytes(int ring_words) { return 96 + (size_t)ring_words * 4 + (size_t)(ring_words / 2) * 4; }
 
-void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words,
-                    size_t lds_bytes, hipStream_t s) {
-  if (nwg <= 0) return;
-  const size_t lane_bytes = (size_t)nslots * HfLaneLdsBytes(32);   // tables in global memory: always the wide window
+void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int ring_words,
+                    size_t lds_bytes, size_t lane_bytes, hipStream_t s) {
+  if (nwg <= 0) return;   // lds_bytes: tables + lanes of the largest workgroup; lane_bytes: the lanes alone (tables in global memory)
   (void)ring_words;   // one window size: 32 words (a 16-word variant paid off while the coefficient orders lived in LDS; not any more)
   if (lds_bytes) {
     RaiseLds((const void*)hf_decode_kernel<true, 32>, lds_bytes);
-    hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride, nslots);
+    hipLaunchKernelGGL((hf_decode_kernel<true, 32>), dim3(nwg), dim3(threads), lds_bytes, s, imgs, tasks, lane_stride);
   } else {
     RaiseLds((const void*)hf_decode_kernel<false, 32>, lane_bytes);
-    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride, nslots);
+    hipLaunchKernelGGL((hf_decode_kernel<false, 32>), dim3(nwg), dim3(threads), lane_bytes, s, imgs, tasks, lane_stride);
   }
 }
 

@@ -11,8 +11,8 @@ void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, siz
 void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);
-void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int nslots, int ring_words, size_t lds_bytes,
-                    hipStream_t s);
+void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int ring_words, size_t lds_bytes,
+                    size_t lane_bytes, hipStream_t s);
 void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical

@@ -552,9 +552,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   int n_alpha_wg = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_alpha_wg += ((int)frames[i].ng + per_alpha_wg - 1) / per_alpha_wg;
+  // LF groups per wavefront of the LF phase-A kernel.  Measured on MI355X: the 64 LF groups of a 16384^2 frame in ONE wavefront (every
+  // lane walking its own divergent stream) took 68 ms against 33 ms for the four of a 4K frame; one group per wavefront is no faster
+  // for a single frame and much slower for a batch (384 frames: 44 -> 67 ms, four times the wavefronts for the same tokens).  So: four
+  // per wavefront, more only when a batch brings tens of thousands of LF groups.
+  int lf_per_wave = 4;
+  while (lf_per_wave < 64 && total_lf / lf_per_wave > 4096) lf_per_wave *= 2;
   int n_lf_ans = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_lf_ans += ((int)frames[i].nlf + 63) / 64;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_lf_ans += ((int)frames[i].nlf + lf_per_wave - 1) / lf_per_wave;
   const size_t off_lf_ans_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_lf_ans));
   const size_t off_mod_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_mod_tasks));
   const size_t off_alpha_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_alpha_wg));
@@ -802,7 +808,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (uint32_t g = lfy0 * f.xlf; g < std::min<uint32_t>(f.nlf, lfy1 * f.xlf); g++) lf_tasks[nlf_t++] = SectionTask{i, (int32_t)g, 1, 0};
     {
       const uint32_t l0 = lfy0 * f.xlf, l1 = std::min<uint32_t>(f.nlf, lfy1 * f.xlf);
-      for (uint32_t g = l0; g < l1; g += 64) lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(64, l1 - g), 0};
+      for (uint32_t g = l0; g < l1; g += lf_per_wave)
+        lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>((uint32_t)lf_per_wave, l1 - g), 0};
     }
     const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
     const uint32_t pw = (uint32_t)hf_per_wg(f);

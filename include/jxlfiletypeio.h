@@ -179,6 +179,10 @@ JXLFILETYPEIO_API int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** na
 JXLFILETYPEIO_API int32_t jxlhip_stage_totals(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity, int32_t* batches,
                                               int32_t reset);
 
+/* Host-only (no GPU): the embedded ICC profile as LoadImage would hand it to setIccProfile (reference Decoder/JxlDecoder.cpp:652-682);
+ * returns its size (0: none) and copies up to `capacity` bytes. */
+JXLFILETYPEIO_API size_t jxlhip_parse_icc(const uint8_t* data, size_t size, uint8_t* dst, size_t capacity, DecoderStatus* status, ErrorInfo* err);
+
 #ifdef __cplusplus
 }
 static_assert(sizeof(BitmapData) == 24, "BitmapData layout");

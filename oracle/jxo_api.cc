@@ -1,6 +1,7 @@
 // ORACLE — test infrastructure only (see jxo_common.h header).
 // Plain C entry points for ctypes (tests/, bench.py cpu_baseline leg, smoke()).
 #include "jxo_codec.h"
+#include "jxo_icc.h"
 #include <string>
 
 using namespace jxo;
@@ -85,6 +86,33 @@ struct JxoEncodeParams {
   int32_t colour;        // EncodeParams::colour
 };
 
+// Optional inputs of the NEXT jxo_encode call on this thread (kept out of the parameter struct so that its layout stays put):
+// an ICC profile to embed, and whether the 4 / 5 channels are CMYK[A].
+static thread_local std::vector<uint8_t> g_next_icc;
+static thread_local bool g_next_cmyk = false;
+void jxo_set_next_icc(const uint8_t* icc, size_t size, int cmyk) {
+  g_next_icc.assign(icc ? icc : nullptr, icc ? icc + size : nullptr);
+  g_next_cmyk = cmyk != 0;
+}
+// ICC predicted stream -> profile with the oracle's own reader (0: the stream is invalid)
+size_t jxo_icc_from_stream(const uint8_t* enc, size_t size, uint8_t* dst, size_t capacity) {
+  try {
+    std::vector<uint8_t> out = IccFromStream(std::vector<uint8_t>(enc, enc + size));
+    for (size_t i = 0; i < out.size() && i < capacity; i++) dst[i] = out[i];
+    return out.size();
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return 0;
+  }
+}
+size_t jxo_icc_to_stream(const uint8_t* icc, size_t size, uint8_t* dst, size_t capacity) {
+  std::vector<uint8_t> out = IccToStream(std::vector<uint8_t>(icc, icc + size));
+  for (size_t i = 0; i < out.size() && i < capacity; i++) dst[i] = out[i];
+  return out.size();
+}
+size_t jxo_image_icc(const JxoImage* im, const uint8_t** ptr) { *ptr = im->r.icc.data(); return im->r.icc.size(); }
+int jxo_image_cmyk(const JxoImage* im) { return im->r.cmyk ? 1 : 0; }
+
 JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, const JxoEncodeParams* ep, const uint8_t* exif,
                      size_t exif_size, const uint8_t* xmp, size_t xmp_size) {
   try {
@@ -99,6 +127,8 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.orientation = ep->orientation ? ep->orientation : 1;
     p.float_samples = ep->float_samples;
     p.colour = ep->colour;
+    p.icc.swap(g_next_icc); g_next_icc.clear();
+    p.cmyk = g_next_cmyk; g_next_cmyk = false;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

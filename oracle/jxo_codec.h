@@ -33,7 +33,10 @@ struct DecodeResult {
   int out_w = 0, out_h = 0;     // size of `pixels`: the frame size with the header's orientation applied (5..8 swap the sides)
   int bits_out = 8;             // 8: `pixels` holds u8 samples; 16: little-endian u16 samples (streams of more than 8 bits per sample)
   bool out_float = false;       // float-sample streams: bits_out 16 = binary16, 32 = binary32 (little-endian bit patterns)
-  std::vector<uint8_t> pixels;  // interleaved, tight rows
+  std::vector<uint8_t> pixels;  // interleaved, tight rows; CMYK (black extra channel): C, M, Y, K [, A] with 0 = no ink (the
+                                // reference inverts the stored samples for its host, Decoder/JxlDecoder.cpp:159-215)
+  std::vector<uint8_t> icc;     // embedded ICC profile (what the reference hands to setIccProfile for original-profile streams)
+  bool cmyk = false;
   StageDump dump;
 };
 
@@ -68,6 +71,8 @@ struct EncodeParams {
   // 4: BT.2100 primaries, PQ (intensity target 10000); 5: linear sRGB; 6: HLG written to the header only (refusal tests)
   int colour = 0;
   int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
+  std::vector<uint8_t> icc;     // embedded ICC profile instead of the enumerated colour encoding
+  bool cmyk = false;            // lossless only: nch 4 / 5 = C, M, Y, K [, A] as STORED (0 = full ink); K goes to a black extra channel
 };
 
 // rgba: interleaved RGBA8 (or RGB8 / Gray8 / GrayA8 according to nch), tight rows.

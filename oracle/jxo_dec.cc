@@ -2,6 +2,7 @@
 // Whole-frame decode: the CPU restatement of what JxlDecoderProcessInput does for the
 // reference at src/JxlFileTypeIO/Decoder/JxlDecoder.cpp:252 (frame) and :454 (headers).
 #include "jxo_codec.h"
+#include "jxo_icc.h"
 #include "jxo_entropy.h"
 #include "jxo_modular.h"
 #include <atomic>
@@ -505,7 +506,25 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   ImageMetadata& m = out.meta;
   ReadSizeHeader(br, &m.xsize, &m.ysize);
   ReadImageMetadata(br, m);
-  JXO_CHECK(!m.color.want_icc, "embedded ICC profiles are not supported yet");
+  if (m.color.want_icc) {   // the embedded profile
+    const uint64_t n = br.U64();
+    JXO_CHECK(n > 0 && n < (1u << 28), "ICC profile: encoded size");
+    EntropyCode code;
+    DecodeHistograms(br, kNumIccContexts, code);
+    EntropyReader rd;
+    rd.Init(code, br);
+    std::vector<uint8_t> enc((size_t)n);
+    for (size_t i = 0; i < enc.size(); i++) {
+      const uint32_t v = rd.Read(IccByteContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0));
+      JXO_CHECK(v < 256, "ICC profile: byte range");
+      enc[i] = (uint8_t)v;
+    }
+    JXO_CHECK(rd.CheckFinal(), "ICC profile: final ANS state");
+    out.icc = IccFromStream(enc);
+    // An XYB stream with a profile would need that profile evaluated (colour management); original-profile streams carry their
+    // samples in the profile's space untouched.
+    JXO_CHECK(!m.xyb_encoded, "XYB streams with an ICC profile need colour management, which the oracle does not have");
+  }
   JXO_CHECK(m.exp_bits ? ((m.bits == 32 && m.exp_bits == 8) || (m.bits == 16 && m.exp_bits == 5)) : (m.bits >= 1 && m.bits <= 16),
             "only integer samples of up to 16 bits and binary16 / binary32 float samples are supported yet");
   br.AlignByte();
@@ -591,7 +610,11 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
   // ------------------------------------------------------------- colour pipeline
   const int ncolor = m.num_color_channels();
   const int alpha_ec = m.alpha_index();
-  const int nch = ncolor + (alpha_ec >= 0 ? 1 : 0);
+  int black_ec = -1;
+  for (size_t i = 0; i < m.ec.size(); i++) if (m.ec[i].type == 4 && black_ec < 0) black_ec = (int)i;
+  out.cmyk = black_ec >= 0;   // Decoder/JxlDecoder.cpp:110-157: one black channel + at most one alpha channel
+  if (out.cmyk) JXO_CHECK(ncolor == 3 && f.encoding == 1 && !m.exp_bits && m.bits == 8 && m.ec[black_ec].bits == 8, "CMYK: 8-bit lossless streams only");
+  const int nch = ncolor + (out.cmyk ? 1 : 0) + (alpha_ec >= 0 ? 1 : 0);
   out.num_channels = nch;
   // output sample type by the colour channels' depth (Decoder/JxlDecoder.cpp:510-556 of the reference)
   out.out_float = m.exp_bits != 0;
@@ -658,7 +681,17 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
       const Channel& ch = d.full.ch[c];
       JXO_CHECK(ch.w == w && ch.h == h, "modular colour channel size");
       for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) put(y, x, c, SampleToOut(ch.Row(y)[x], m.bits, m.exp_bits, out.bits_out, out.out_float));
+        for (int x = 0; x < w; x++) {
+          uint32_t v = SampleToOut(ch.Row(y)[x], m.bits, m.exp_bits, out.bits_out, out.out_float);
+          if (out.cmyk) v = 255 - v;   // stored 0 = full ink; the host wants 0 = no ink (Decoder/JxlDecoder.cpp:199-202)
+          put(y, x, c, v);
+        }
+    }
+    if (out.cmyk) {
+      const Channel& ch = d.full.ch[ncolor + black_ec];
+      JXO_CHECK(ch.w == w && ch.h == h, "black channel size");
+      for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) put(y, x, 3, 255 - SampleToOut(ch.Row(y)[x], 8, 0, 8, false));
     }
   }
   if (alpha_ec >= 0) {
@@ -672,7 +705,7 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     JXO_CHECK(!m.ec[alpha_ec].alpha_associated, "premultiplied alpha is not supported yet");
     if (dump) dump->alpha = ch.d;
     for (int y = 0; y < h; y++)
-      for (int x = 0; x < w; x++) put(y, x, ncolor, SampleToOut(ch.Row(y)[x], ae.bits, ae.exp_bits, out.bits_out, out.out_float));
+      for (int x = 0; x < w; x++) put(y, x, nch - 1, SampleToOut(ch.Row(y)[x], ae.bits, ae.exp_bits, out.bits_out, out.out_float));
   }
   // ---- orientation: the decoder library behind the reference hands out the image as it is meant to be displayed
   // (keep_orientation is off by default), sides swapped for orientations 5..8

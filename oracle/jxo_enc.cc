@@ -4,6 +4,7 @@
 // Streams are single-frame, single-pass; lossy = VarDCT+XYB with lossless Modular alpha,
 // lossless = Modular RGB(A) with RCT.  Not a port of libjxl's heuristics.
 #include "jxo_codec.h"
+#include "jxo_icc.h"
 #include "jxo_entropy.h"
 #include "jxo_modular.h"
 
@@ -620,7 +621,8 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
 
 std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nch, const EncodeParams& p, const uint8_t* exif,
                                size_t exif_size, const uint8_t* xmp, size_t xmp_size) {
-  JXO_CHECK(nch >= 1 && nch <= 4 && w > 0 && h > 0, "bad image");
+  JXO_CHECK(nch >= 1 && nch <= (p.cmyk ? 5 : 4) && w > 0 && h > 0, "bad image");
+  JXO_CHECK(!p.cmyk || (p.lossless && nch >= 4 && !p.icc.empty()), "CMYK: lossless, 4 or 5 channels, with a (CMYK) ICC profile");
   ImageMetadata m;
   m.xsize = w; m.ysize = h;
   m.xyb_encoded = !p.lossless;
@@ -639,13 +641,17 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
     default: JXO_CHECK(false, "unknown colour option");
   }
   if (nch < 3) m.color.primaries = 1;   // gray: no primaries
+  if (!p.icc.empty()) m.color.want_icc = true;
   JXO_CHECK(p.bits >= 8 && p.bits <= 16, "bits per sample must be 8..16");
   JXO_CHECK(p.float_samples == 0 || p.float_samples == 16 || p.float_samples == 32, "float samples are binary16 or binary32");
   m.bits = p.float_samples ? (uint32_t)p.float_samples : (uint32_t)p.bits;
   m.exp_bits = p.float_samples == 32 ? 8 : (p.float_samples == 16 ? 5 : 0);
   JXO_CHECK(p.orientation >= 1 && p.orientation <= 8, "orientation must be 1..8");
   m.orientation = (uint32_t)p.orientation;
-  if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; }
+  if (p.cmyk) {   // "the RGB samples are to be interpreted as CMY" + a black extra channel (+ alpha)
+    m.ec.push_back(ExtraChannelInfo()); m.ec.back().type = 4; m.ec.back().bits = m.bits;
+    if (nch == 5) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; }
+  } else if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; }
   FrameHeader f;
   f.ec_upsampling.assign(m.ec.size(), 1);
   std::vector<uint8_t> frame;
@@ -671,6 +677,17 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   bw.Write(8, 0x0A);
   WriteSizeHeader(bw, w, h);
   WriteImageMetadata(bw, m);
+  if (m.color.want_icc) {   // the profile follows the metadata: predicted byte stream, 41 contexts on the two bytes before
+    const std::vector<uint8_t> enc = IccToStream(p.icc);
+    bw.U64(enc.size());
+    std::vector<Token> tok;
+    for (size_t i = 0; i < enc.size(); i++) tok.emplace_back(IccByteContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0), enc[i]);
+    EncCode code;
+    EncOptions eo;
+    eo.max_clusters = 16;
+    BuildAndWriteCode({&tok}, kNumIccContexts, eo, bw, code);
+    WriteTokens(tok, code, bw);
+  }
   bw.AlignByte();
   std::vector<uint8_t> cs = bw.Finish();
   cs.insert(cs.end(), frame.begin(), frame.end());

@@ -85,9 +85,9 @@ static void ReadColorEncoding(BitReader& br, ColorEncoding& c) {
 static void WriteColorEncoding(BitWriter& bw, const ColorEncoding& c) {
   bw.Bool(c.all_default);
   if (c.all_default) return;
-  JXO_CHECK(!c.want_icc, "ICC profiles are not written by the oracle encoder");
-  bw.Bool(false);
+  bw.Bool(c.want_icc);
   bw.Enum(c.color_space);
+  if (c.want_icc) return;
   if (c.color_space != 2) {
     JXO_CHECK(c.white_point != 2, "custom white point not written");
     bw.Enum(c.white_point);

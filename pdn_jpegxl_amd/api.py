@@ -65,7 +65,7 @@ class ImageInfo(C.Structure):
                 ("reserved", C.c_int32)]
 
 
-EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_decoder_create", "jxlhip_decoder_destroy", "jxlhip_peek",
+EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_parse_icc", "jxlhip_decoder_create", "jxlhip_decoder_destroy", "jxlhip_peek",
            "jxlhip_decode_batch", "jxlhip_finish", "jxlhip_read_plane", "jxlhip_set_option", "jxlhip_stage_times", "jxlhip_stage_totals"]
 
 _lib = None
@@ -196,7 +196,7 @@ def load_image(data, fail_at=None):
         img.trace.append("setLayerData")
         if fail_at == "setLayerData":
             return False
-        nch = (1 if img.format == "Gray" else 3) + (1 if img.has_transparency else 0)
+        nch = {"Gray": 1, "Rgb": 3, "Cmyk": 4}[img.format] + (1 if img.has_transparency else 0)
         n = img.width * img.height * nch
         # ImageChannelRepresentation (Common.h:33-39): Uint8, Uint16, Float16, Float32
         dt = (np.uint8, np.uint16, np.float16, np.float32)[img.channel_representation]

@@ -7,8 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "libJpegXLFileTypeIO_X64.so"
-SOURCES = ["kernels.hip", "entropy_kernels.hip", "tile_kernels.hip", "encode_kernels.hip", "host_parse.cc", "host_write.cc", "decoder.cc", "encoder.cc"]
-HEADERS = ["dev_types.h", "dev_util.h", "enc_types.h", "kernels.h", "host_parse.h", "host_write.h", os.path.join("..", "..", "include", "jxlfiletypeio.h")]
+SOURCES = ["kernels.hip", "entropy_kernels.hip", "tile_kernels.hip", "encode_kernels.hip", "host_parse.cc", "host_write.cc", "icc.cc", "decoder.cc", "encoder.cc"]
+HEADERS = ["dev_types.h", "dev_util.h", "enc_types.h", "kernels.h", "host_parse.h", "host_write.h", "icc.h", os.path.join("..", "..", "include", "jxlfiletypeio.h")]
 
 
 def lib_path():

@@ -19,6 +19,7 @@
 #include <vector>
 #include "../../include/jxlfiletypeio.h"
 #include "host_parse.h"
+#include "icc.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -380,6 +381,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t scan[kNumQuantTables] = {};   // frames with their own coefficient orders: scan lists of the affected quant tables
+    size_t trc_lut = 0;                  // tone-curve tables of an evaluated ICC profile (+1; 0: none)
     size_t z_cellinfo, z_status, centries, cblk;
     std::vector<size_t> mod_planes;
     size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
@@ -433,6 +435,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     }
     const bool resident = dev_data && dev_data[i] && f.cs_contiguous;
     l.cs = resident ? 0 : blob.Take(f.cs_size + 16);
+    if (PlanColor(f).transfer == 5) l.trc_lut = blob.Take(4 * 3 * 4096, 256) + 1;
     l.z_cellinfo = ws_zero.Take(4 * cells);
     l.z_status = ws_zero.Take(64);
     {
@@ -487,7 +490,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (parse_status[i] != DecoderStatus_Ok || frames[i].orientation == 1) continue;
     const ParsedFrame& f = frames[i];
     if (band_rows > 0) { parse_status[i] = DecoderStatus_DecodeError; parse_msg[i] = "band decode of a frame with an orientation is not supported"; continue; }
-    L[i].orient_tmp = ws.Take((size_t)f.xsize * f.ysize * (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * OutBytesPerSample(f));
+    L[i].orient_tmp = ws.Take((size_t)f.xsize * f.ysize * (f.ncolor + (f.black_index >= 0 ? 1 : 0) + (f.alpha_index >= 0 ? 1 : 0)) * OutBytesPerSample(f));
   }
   // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
   // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
@@ -614,7 +617,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.dec_gy0 = std::max(0, b0 - 1); d.dec_gy1 = std::min<int>((int)f.yg, b1 + 1);
     d.band_y0 = std::min<int>(b0 * kGroupDim, (int)f.ysize); d.band_y1 = std::min<int>(b1 * kGroupDim, (int)f.ysize);
     const ColorPlan plan = PlanColor(f);
-    d.to_srgb = plan.transfer;   // 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+    d.to_srgb = plan.transfer;   // 0 linear, 1 sRGB, 2 BT.709, 3 PQ, 5 tables
+    if (plan.transfer == 5 && l.trc_lut) {
+      memcpy(h_blob + l.trc_lut - 1, plan.trc_lut.data(), 4 * 3 * 4096);
+      d.trc_lut = (const float*)(d_blob + l.trc_lut - 1);
+    }
     d.pq_scale = f.intensity_target * 1e-4f;
     auto put = [&](size_t off, const void* src, size_t bytes) { if (bytes) memcpy(h_blob + off, src, bytes); };
     put(l.sec_off, f.sec_off.data(), 8 * f.sec_off.size());
@@ -651,7 +658,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (f.encoding == 1) {
       d.is_modular = 1;
       d.w8 = d.h8 = d.wt = d.ht = d.wp = d.hp = 0;   // nothing of the VarDCT pipeline runs for this image
+      d.cmyk = f.black_index >= 0 ? 1 : 0;
+      d.black_bits = d.cmyk ? (int32_t)f.ec[f.black_index].bits : 8;
+      d.nch_out = d.ncolor + d.cmyk + d.has_alpha;
       d.mod_nch = d.nch_out;
+      // stream order: colour channels, then the extra channels as listed; output order: colour, black, alpha
+      for (int c = 0; c < d.ncolor; c++) d.mod_out_pos[c] = c;
+      if (d.cmyk) d.mod_out_pos[d.ncolor + f.black_index] = d.ncolor;
+      if (d.has_alpha) d.mod_out_pos[d.ncolor + f.alpha_index] = d.nch_out - 1;
       d.group_dim = (int32_t)f.group_dim;
       d.single = f.single ? 1 : 0;
       d.mod_data_bits = f.mod_data_bits;
@@ -891,7 +905,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].orientation != 1) {
       const ParsedFrame& f = frames[i];
-      LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.alpha_index >= 0 ? 1 : 0)) * (int)OutBytesPerSample(f),
+      LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.black_index >= 0 ? 1 : 0) + (f.alpha_index >= 0 ? 1 : 0)) * (int)OutBytesPerSample(f),
                    (int)f.orientation, stream);
     }
   for (int i = 0; i < n; i++)
@@ -1073,7 +1087,7 @@ DecoderStatus jxlhip_peek(const uint8_t* data, size_t size, JxlHipImageInfo* inf
     ParseFile(data, size, true, f);
     info->width = f.orientation >= 5 ? f.ysize : f.xsize; info->height = f.orientation >= 5 ? f.xsize : f.ysize;   // as displayed
     info->has_alpha = f.alpha_index >= 0;
-    info->num_channels = f.ncolor + info->has_alpha;
+    info->num_channels = f.ncolor + (f.black_index >= 0 ? 1 : 0) + info->has_alpha;
     info->bytes_per_sample = (int32_t)OutBytesPerSample(f);
     info->reserved = f.exp_bits ? 1 : 0;   // float samples
     info->xsize_blocks = f.w8; info->ysize_blocks = f.h8;
@@ -1211,7 +1225,7 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     for (auto& e : f.ec) { if (e.type == 4) black++; if (e.type == 0) alphas++; }
     if ((f.ncolor != 1 && f.ncolor != 3) || black > 1 || alphas > 1) return DecoderStatus_UnsupportedChannelFormat;   // :485-490
     const bool has_alpha = f.alpha_index >= 0;
-    if (black) { SetErr(err, "CMYK images are not supported on the GPU path yet."); return DecoderStatus_DecodeError; }
+    const bool cmyk = black == 1;   // ExtraChannelsAreSupported + DecoderImageFormat::Cmyk (:110-157, :499-503)
     // sample type by bit depth (Decoder/JxlDecoder.cpp:510-556)
     int rep = ImageChannelRepresentation_Uint8;
     if (f.exp_bits > 0) {
@@ -1224,19 +1238,26 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     }
     const bool swap_sides = f.orientation >= 5;   // the host is told the size as displayed
     cb->setBasicInfo((int32_t)(swap_sides ? f.ysize : f.xsize), (int32_t)(swap_sides ? f.xsize : f.ysize),
-                     f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb, (ImageChannelRepresentation)rep, has_alpha);   // :558
+                     cmyk ? DecoderImageFormat_Cmyk : (f.ncolor == 1 ? DecoderImageFormat_Gray : DecoderImageFormat_Rgb), (ImageChannelRepresentation)rep,
+                     has_alpha);   // :558
     // colour encoding -> KnownColorProfile (Decoder/JxlDecoder.cpp:36-108); anything else would take the reference's ICC route
     {
-      const int prof = PlanColor(f).known_profile;
-      if (prof < 0) { SetErr(err, "This colour encoding needs an ICC profile, which the GPU path does not build yet."); return DecoderStatus_DecodeError; }
-      if (!cb->setKnownColorProfile((KnownColorProfile)prof)) return DecoderStatus_CreateMetadataError;   // :648-651
+      const ColorPlan plan = PlanColor(f);
+      if (plan.report_icc) {   // the target-data profile is the embedded ICC profile (:652-682)
+        if (!f.icc.empty() && !cb->setIccProfile(f.icc.data(), f.icc.size())) return DecoderStatus_CreateMetadataError;
+      } else if (plan.known_profile < 0) {
+        SetErr(err, "This colour encoding needs a synthesised ICC profile, which the GPU path does not build yet.");
+        return DecoderStatus_DecodeError;
+      } else if (!cb->setKnownColorProfile((KnownColorProfile)plan.known_profile)) {
+        return DecoderStatus_CreateMetadataError;   // :648-651
+      }
     }
     if (f.exif && f.exif_size && !cb->setExif(const_cast<uint8_t*>(f.exif), f.exif_size)) return DecoderStatus_CreateMetadataError;   // :764
     for (auto& x : f.xml)
       if (!cb->setXmp(const_cast<uint8_t*>(x.first), x.second)) return DecoderStatus_CreateMetadataError;   // :775-782
     // ---- pass 2: the frame (Decoder/JxlDecoder.cpp:217-410)
     JxlHipDecoder* dec = ThreadDecoder();
-    const int nch = f.ncolor + (has_alpha ? 1 : 0);
+    const int nch = f.ncolor + (cmyk ? 1 : 0) + (has_alpha ? 1 : 0);   // CMYK: C M Y K [A], inverted for the host on the device (:159-215)
     const size_t bytes = (size_t)f.xsize * f.ysize * nch * OutBytesPerSample(f);   // tightly packed, :291-313
     dec->EnsureLoadImageBuffers(bytes);
     uint8_t* const d_out = dec->li_dev;
@@ -1318,6 +1339,43 @@ JXLFILETYPEIO_API DecoderStatus jxlhip_parse_check(const uint8_t* data, size_t s
     SetErr(err, "%s", e.what());
     return DecoderStatus_DecodeError;
   }
+}
+
+// Host-only: the embedded ICC profile as LoadImage would hand it to setIccProfile (0: the stream has none).
+JXLFILETYPEIO_API size_t jxlhip_parse_icc(const uint8_t* data, size_t size, uint8_t* dst, size_t capacity, DecoderStatus* status, ErrorInfo* err) {
+  if (status) *status = DecoderStatus_Ok;
+  if (!data) { if (status) *status = DecoderStatus_NullParameter; return 0; }
+  try {
+    ParsedFrame f;
+    ParseFile(data, size, true, f);
+    if (dst && capacity) memcpy(dst, f.icc.data(), std::min(f.icc.size(), capacity));
+    return f.icc.size();
+  } catch (const ParseError& e) {
+    SetErr(err, "%s", e.what());
+    if (status) *status = (DecoderStatus)e.status;
+  } catch (const std::exception& e) {
+    SetErr(err, "%s", e.what());
+    if (status) *status = DecoderStatus_DecodeError;
+  }
+  return 0;
+}
+
+// Host-only test hooks of icc.cc: the predicted stream -> profile (returns the size, 0 on failure), and the colour model of a
+// matrix / TRC profile (model[0..8] linear sRGB -> profile RGB, model[9..17] the inverse; returns 1 if the profile is of that kind).
+JXLFILETYPEIO_API size_t jxlhip_icc_unpredict(const uint8_t* enc, size_t size, uint8_t* dst, size_t capacity, ErrorInfo* err) {
+  std::vector<uint8_t> e(enc, enc + size), out;
+  std::string why;
+  if (!IccUnpredict(e, &out, &why)) { SetErr(err, "%s", why.c_str()); return 0; }
+  if (dst && capacity) memcpy(dst, out.data(), std::min(out.size(), capacity));
+  return out.size();
+}
+JXLFILETYPEIO_API int32_t jxlhip_icc_model(const uint8_t* icc, size_t size, double* model, float* to_linear, float* from_linear) {
+  IccModel m;
+  if (!IccBuildModel(icc, size, &m)) return 0;
+  for (int k = 0; k < 9; k++) { model[k] = m.from_linear_srgb[k]; model[9 + k] = m.to_linear_srgb[k]; }
+  if (to_linear) for (int c = 0; c < 3; c++) memcpy(to_linear + 256 * c, m.to_linear[c].data(), 256 * 4);
+  if (from_linear) for (int c = 0; c < 3; c++) memcpy(from_linear + kIccInvLut * c, m.from_linear[c].data(), kIccInvLut * 4);
+  return m.gray ? 2 : 1;
 }
 
 // Host-only: byte sizes of the TOC sections in logical order (LfGlobal, LF groups, HfGlobal, pass groups).  Returns their number.

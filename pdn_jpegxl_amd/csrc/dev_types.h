@@ -69,8 +69,9 @@ struct DevImage {
   // geometry
   int32_t w, h, w8, h8, wp, hp, wt, ht;
   int32_t xg, yg, ng, xlf, ylf, nlf;
-  int32_t ncolor, has_alpha, nch_out, to_srgb;   // to_srgb: transfer function of the output, 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+  int32_t ncolor, has_alpha, nch_out, to_srgb;   // to_srgb: transfer function of the output, 0 linear, 1 sRGB, 2 BT.709, 3 PQ, 5 tables
   float pq_scale, pad_color;                     // intensity target / 10000 (PQ)
+  const float* trc_lut;                          // to_srgb == 5: 3 x 4096 tables, sqrt(linear) -> encoded (an evaluated ICC profile)
   // sample depths: the colour channels / the alpha channel as coded (integers of 1..16 bits, binary16 / binary32 floats), and the
   // output sample type chosen from the colour depth like the reference does (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32
   int32_t sample_bits, alpha_bits, out_bits, out_float;   // out_float: out_bits 16 / 32 are binary16 / binary32 samples
@@ -144,7 +145,9 @@ struct DevImage {
   // group, from the GlobalModular stream), then inverse colour transforms and interleaving in modular_out_kernel
   int32_t is_modular, mod_nch, group_dim, mod_ntr;
   int32_t mod_tr[4][2];     // reversible colour transforms in stream order: begin channel, type (frames without Squeeze: undone in modular_out)
-  int32_t* mod_plane[4];    // the image channels, w*h each
+  int32_t* mod_plane[5];    // the image channels in stream order (colour, then the extra channels), w*h each
+  int32_t mod_out_pos[5];   // output position of each of them (CMYK: C M Y K [A] whatever the order of the black and alpha channels)
+  int32_t cmyk, black_bits; // a black extra channel: DecoderImageFormat::Cmyk; the host wants 0 = no ink, the stream stores 0 = full ink
   const ModChanDev* mod_chan;   // coded channels (after the transforms), mod_ncoded entries
   int32_t mod_ncoded, mod_first_group;   // channels before mod_first_group are coded in the GlobalModular stream
   ChanDesc* mod_desc;       // [section][coded channel]; sections: 0 global, 1 + g LF group g, 1 + nlf + g pass group g

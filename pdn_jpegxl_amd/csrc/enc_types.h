@@ -36,6 +36,9 @@ struct EncImage {
   const uint8_t* bgra;
   int32_t stride, pad0;
   uint32_t* flags;          // [0] some pixel is not gray, [1] some pixel has alpha < 255
+  // documents with an (evaluated, matrix / TRC) ICC profile: 3 x 256 samples -> linear of the profile, then 3x3 -> linear sRGB
+  const float* icc_lin;     // nullptr: the samples are sRGB
+  float icc_to_srgb[9];
   // planes
   float* xyb[3];            // w*h
   float* pad[3];            // wp*hp: (inverse-Gaborish sharpened) XYB, edge-replicated to whole 8x8 cells

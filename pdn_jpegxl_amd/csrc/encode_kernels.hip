@@ -70,7 +70,13 @@ __global__ void enc_xyb_kernel(EncImage im) {
       const float v = (float)v8 * (1.0f / 255.0f);
       return v <= 0.04045f ? v / 12.92f : powf((v + 0.055f) / 1.055f, 2.4f);
     };
-    const float r = lin(r8), g = lin(g8), b = lin(b8);
+    float r = lin(r8), g = lin(g8), b = lin(b8);
+    if (im.icc_lin) {   // the document's own tone curves and primaries
+      const float pr = im.icc_lin[r8], pg = im.icc_lin[256 + g8], pb = im.icc_lin[512 + b8];
+      r = im.icc_to_srgb[0] * pr + im.icc_to_srgb[1] * pg + im.icc_to_srgb[2] * pb;
+      g = im.icc_to_srgb[3] * pr + im.icc_to_srgb[4] * pg + im.icc_to_srgb[5] * pb;
+      b = im.icc_to_srgb[6] * pr + im.icc_to_srgb[7] * pg + im.icc_to_srgb[8] * pb;
+    }
     float mr = kM[0] * r + kM[1] * g + kM[2] * b + kB;
     float mg = kM[3] * r + kM[4] * g + kM[5] * b + kB;
     float mb = kM[6] * r + kM[7] * g + kM[8] * b + kB;

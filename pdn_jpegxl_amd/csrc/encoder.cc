@@ -19,6 +19,7 @@
 #include "enc_types.h"
 #include "host_parse.h"
 #include "host_write.h"
+#include "icc.h"
 #include "kernels.h"
 
 namespace jxlhip {
@@ -152,8 +153,6 @@ void EmitFile(const std::vector<uint8_t>& codestream, const EncoderImageMetadata
 void BeginImage(const BitmapData* bmp, const EncoderImageMetadata* md, Arena& A, EncImage& im, ProgressProc progress) {
   const uint32_t w = bmp->width, h = bmp->height;
   if (!w || !h || !bmp->scan0 || bmp->stride < (uint64_t)w * 4) throw EncFail(EncoderStatus_EncodeError, "invalid bitmap");
-  if (md->iccProfile && md->iccProfileSize)
-    throw EncFail(EncoderStatus_EncodeError, "embedded ICC profiles are not supported on the MI355X encode path yet");
   memset(&im, 0, sizeof(im));
   im.w = (int32_t)w; im.h = (int32_t)h;
   im.w8 = (int32_t)((w + 7) / 8); im.h8 = (int32_t)((h + 7) / 8);
@@ -168,6 +167,7 @@ void BeginImage(const BitmapData* bmp, const EncoderImageMetadata* md, Arena& A,
   uint32_t flags[2] = {0, 0};
   ENC_HIP(hipMemcpy(flags, im.flags, sizeof(flags), hipMemcpyDeviceToHost));
   im.gray = flags[0] ? 0 : 1;       // every pixel r == g == b and no ICC profile: one colour channel (:67-70)
+  if (md->iccProfile && md->iccProfileSize) im.gray = 0;   // an RGB profile must keep describing RGB samples (:71-75)
   im.has_alpha = flags[1] ? 1 : 0;  // some pixel a < 255 (:54-57)
   Progress(progress, 5);
 }
@@ -236,6 +236,7 @@ void EncodeLossless(const BitmapData* bmp, const EncoderImageMetadata* md, IOCal
   Progress(progress, 30);
   EncImageInfo ii;
   ii.xsize = (uint32_t)im.w; ii.ysize = (uint32_t)im.h; ii.gray = im.gray; ii.alpha = im.has_alpha; ii.xyb = false;
+  ii.icc = md->iccProfile; ii.icc_size = md->iccProfile ? md->iccProfileSize : 0;
   EncFrameInfo fi;
   fi.encoding = 1; fi.group_size_shift = 1; fi.gab = false; fi.epf_iters = 0;
   BitWriter cs;
@@ -265,6 +266,20 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   EncImage im;
   PhaseClock clk;
   BeginImage(bmp, md, A, im, progress);
+  if (md->iccProfile && md->iccProfileSize) {
+    // Lossy with a profile: the samples reach XYB through the profile (the reference leaves that to its encoder library's colour
+    // management, Encoder/JxlEncoder.cpp:258-268).  Matrix / TRC profiles are evaluated here; a profile that would need a full
+    // colour management system cannot be encoded lossily without misrepresenting its colours.
+    IccModel model;
+    if (!IccBuildModel(md->iccProfile, md->iccProfileSize, &model) || model.gray)
+      throw EncFail(EncoderStatus_EncodeError, "this ICC profile is not an RGB matrix/TRC profile: lossy saving needs a full colour management system (save lossless instead)");
+    std::vector<float> lin;
+    for (int c = 0; c < 3; c++) lin.insert(lin.end(), model.to_linear[c].begin(), model.to_linear[c].end());
+    float* d_lin = A.Get<float>(lin.size());
+    ENC_HIP(hipMemcpy(d_lin, lin.data(), lin.size() * 4, hipMemcpyHostToDevice));
+    im.icc_lin = d_lin;
+    for (int k = 0; k < 9; k++) im.icc_to_srgb[k] = (float)model.to_linear_srgb[k];
+  }
   clk.Lap("upload + analysis");
   const uint32_t w = bmp->width, h = bmp->height;
   const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
@@ -375,6 +390,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   // ---- 7. codestream assembly
   EncImageInfo ii;
   ii.xsize = w; ii.ysize = h; ii.gray = im.gray; ii.alpha = im.has_alpha; ii.xyb = true;
+  ii.icc = md->iccProfile; ii.icc_size = md->iccProfile ? md->iccProfileSize : 0;
   BitWriter cs;
   WriteCodestreamHeaders(ii, cs);
   WriteFrameHeader(ii, fi, cs);
@@ -524,6 +540,33 @@ extern "C" JXLFILETYPEIO_API size_t jxlhip_selftest_headers(uint32_t xsize, uint
     WriteToc(sizes, cs);
     std::vector<uint8_t> bytes = cs.Finish();
     bytes.resize(bytes.size() + (size_t)sec_bytes * sizes.size(), 0);
+    std::vector<uint8_t> file = WriteContainer(bytes, nullptr, 0, nullptr, 0);
+    if (file.size() > capacity) return 0;
+    memcpy(dst, file.data(), file.size());
+    return file.size();
+  } catch (...) {
+    return 0;
+  }
+}
+
+// The same with an embedded ICC profile (host only: the ICC stream writer against the parser's reader).
+extern "C" JXLFILETYPEIO_API size_t jxlhip_selftest_headers_icc(uint32_t xsize, uint32_t ysize, int32_t alpha, int32_t lossless, const uint8_t* icc,
+                                                                size_t icc_size, uint8_t* dst, size_t capacity) {
+  try {
+    EncImageInfo ii;
+    ii.xsize = xsize; ii.ysize = ysize; ii.gray = false; ii.alpha = alpha != 0; ii.xyb = !lossless;
+    ii.icc = icc; ii.icc_size = icc_size;
+    EncFrameInfo fi;
+    fi.encoding = lossless ? 1 : 0;
+    fi.gab = !lossless; fi.epf_iters = lossless ? 0 : 1;
+    BitWriter cs;
+    WriteCodestreamHeaders(ii, cs);
+    WriteFrameHeader(ii, fi, cs);
+    const uint32_t ng = ((xsize + 255) / 256) * ((ysize + 255) / 256), nlf = ((xsize + 2047) / 2048) * ((ysize + 2047) / 2048);
+    std::vector<uint32_t> sizes(ng == 1 ? 1 : 2 + nlf + ng, 3);
+    WriteToc(sizes, cs);
+    std::vector<uint8_t> bytes = cs.Finish();
+    bytes.resize(bytes.size() + 3 * sizes.size(), 0);
     std::vector<uint8_t> file = WriteContainer(bytes, nullptr, 0, nullptr, 0);
     if (file.size() > capacity) return 0;
     memcpy(dst, file.data(), file.size());

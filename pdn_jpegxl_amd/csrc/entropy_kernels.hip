@@ -1524,19 +1524,20 @@ __global__ void rct_inverse_kernel(int32_t* p0, int32_t* p1, int32_t* p2, size_t
   }
 }
 
-// Inverse reversible colour transforms (last first), clamp, interleave.
+// Inverse reversible colour transforms (last first), clamp, interleave.  CMYK streams (black extra channel): C, M, Y, K leave as
+// 255 - stored sample (Decoder/JxlDecoder.cpp:159-215: the stream stores 0 = full ink, the host wants 0 = no ink), alpha as it is.
 __global__ void modular_out_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
   if (!im.is_modular) return;
   const size_t n = (size_t)im.w * im.h;
   const int nch = im.mod_nch;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int32_t v[4] = {0, 0, 0, 0};
+    int32_t v[5] = {0, 0, 0, 0, 0};
     for (int c = 0; c < nch; c++) v[c] = im.mod_plane[c][i];
     for (int t = im.mod_ntr - 1; t >= 0; t--) {
       const int bc = im.mod_tr[t][0], type = im.mod_tr[t][1];
       const int perm = type / 7, custom = type % 7;
-      int32_t a = bc == 0 ? v[0] : v[1], b = bc == 0 ? v[1] : v[2], c = bc == 0 ? v[2] : v[3];
+      int32_t a = v[bc], b = v[bc + 1], c = v[bc + 2];
       if (custom == 6) {
         const int32_t tmp = a - (c >> 1), G = c + tmp, B = tmp - (b >> 1), R = B + b;
         a = R; b = G; c = B;
@@ -1549,15 +1550,19 @@ __global__ void modular_out_kernel(const DevImage* imgs) {
       o[perm % 3] = a;
       o[(perm + 1 + perm / 3) % 3] = b;
       o[(perm + 2 - perm / 3) % 3] = c;
-      if (bc == 0) { v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; }
-      else { v[1] = o[0]; v[2] = o[1]; v[3] = o[2]; }
+      v[bc] = o[0]; v[bc + 1] = o[1]; v[bc + 2] = o[2];
     }
-    // colour channels carry sample_bits / sample_exp, the alpha channel (last, if any) alpha_bits / alpha_exp
-    const int ncol = nch - (im.has_alpha ? 1 : 0);
-    for (int c = 0; c < nch; c++)
-      StoreOutSample(im.out, i * nch + c,
-                     SampleToOutBits(v[c], c < ncol ? im.sample_bits : im.alpha_bits, c < ncol ? im.sample_exp : im.alpha_exp, im.out_bits, im.out_float),
-                     im.out_bits);
+    // colour channels carry sample_bits / sample_exp, the alpha channel alpha_bits / alpha_exp, the black channel black_bits
+    const int ncol = im.ncolor;
+    for (int c = 0; c < nch; c++) {
+      const int pos = im.mod_out_pos[c];
+      const bool is_alpha = im.has_alpha && pos == nch - 1;
+      const bool is_black = im.cmyk && pos == 3;
+      uint32_t s = SampleToOutBits(v[c], c < ncol ? im.sample_bits : (is_alpha ? im.alpha_bits : im.black_bits), c < ncol ? im.sample_exp : (is_alpha ? im.alpha_exp : 0),
+                                   im.out_bits, im.out_float);
+      if (im.cmyk && !is_alpha) { (void)is_black; s = 255u - s; }   // 8-bit CMYK only (checked on the host)
+      StoreOutSample(im.out, i * nch + pos, s, im.out_bits);
+    }
   }
 }
 

@@ -1,6 +1,7 @@
 // Host-side frame parser (see host_parse.h).  Restates ISO/IEC 18181-1 header syntax; the
 // reference reaches it via libjxl (Decoder/JxlDecoder.cpp:454 JxlDecoderProcessInput).
 #include "host_parse.h"
+#include "icc.h"
 #include "../../include/jxlfiletypeio.h"
 #include <algorithm>
 #include <cmath>
@@ -1233,7 +1234,25 @@ ColorPlan PlanColor(const ParsedFrame& f) {
   const ColorInfo& c = f.color;
   const uint32_t tf = c.all_default ? 13 : c.tf, wp = c.all_default ? 1 : c.white_point, pr = c.all_default ? 1 : c.primaries;
   const uint32_t cs = c.all_default ? 0 : c.color_space;
-  if (c.want_icc || c.have_gamma || wp != 1) return p;
+  if (c.want_icc) {
+    // Samples that were never converted to XYB (lossless / original-profile streams; CMYK) ARE in the profile's space: hand the
+    // profile over.  An XYB stream would need the profile evaluated (the reference lets the decoder library's colour management do
+    // it, Decoder/JxlDecoder.cpp:617-632); without one this path takes the reference's own fallback (:586-601): sRGB out.
+    if (!f.xyb_encoded) { p.report_icc = true; p.transfer = 0; return p; }
+    IccModel model;
+    if (IccBuildModel(f.icc.data(), f.icc.size(), &model) && model.gray == (cs == 1)) {
+      // a matrix / TRC profile: decode into its space (what the reference gets from its decoder library + colour management, :617-632)
+      p.report_icc = true;
+      p.transfer = 5;
+      for (int k = 0; k < 9; k++) p.from_srgb[k] = (float)model.from_linear_srgb[k];
+      for (int c = 0; c < 3; c++) p.trc_lut.insert(p.trc_lut.end(), model.from_linear[c].begin(), model.from_linear[c].end());
+      return p;
+    }
+    p.transfer = 1;
+    p.known_profile = cs == 1 ? KnownColorProfile_GraySrgbTRC : KnownColorProfile_Srgb;
+    return p;
+  }
+  if (c.have_gamma || wp != 1) return p;
   p.transfer = tf == 8 ? 0 : (tf == 13 ? 1 : (tf == 1 ? 2 : (tf == 16 ? 3 : -1)));
   if (cs == 0) {   // RGB, D65 (Decoder/JxlDecoder.cpp:42-88)
     if (tf == 8) p.known_profile = pr == 1 ? KnownColorProfile_LinearSrgb : (pr == 9 ? KnownColorProfile_Rec2020Linear : -1);
@@ -1351,6 +1370,26 @@ const StaticTables& GetStaticTables() {
   return t;
 }
 
+// The embedded ICC profile: size of the predicted stream, its entropy code (41 contexts on the two previous bytes), the bytes, then
+// the inverse of the predictor (icc.cc).
+void ReadIcc(Bits& r, ParsedFrame& f) {
+  const uint64_t n = r.U64();
+  REQUIRE(n > 0 && n <= kIccMaxEncodedSize && n <= (uint64_t)f.cs_size * 64, "ICC profile: encoded size");
+  HostCode code;
+  ReadCode(r, kIccContexts, code);
+  SymReader sr(code, r);
+  std::vector<uint8_t> enc((size_t)n);
+  for (size_t i = 0; i < enc.size(); i++) {
+    const uint32_t v = sr.Get(IccContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0));
+    REQUIRE(v < 256, "ICC profile: byte out of range");
+    enc[i] = (uint8_t)v;
+    REQUIRE(r.ok(), "truncated ICC profile");
+  }
+  REQUIRE(sr.Final(), "ICC profile: ANS final state");
+  std::string why;
+  if (!IccUnpredict(enc, &f.icc, &why)) Fail(why);
+}
+
 void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame& f) {
   f = ParsedFrame();
   SplitContainer(data, size, f);
@@ -1358,7 +1397,7 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   Bits r(f.cs, f.cs_size);
   r.Skip(16);
   ReadImageHeader(r, f);
-  if (f.color.want_icc) Fail("embedded ICC profiles are not supported yet");
+  if (f.color.want_icc) ReadIcc(r, f);
   r.Align();
   size_t frame_base = r.pos();
   ReadFrameHeader(r, f);
@@ -1371,11 +1410,18 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   // the reference asks for un-premultiplied output (Decoder/JxlDecoder.cpp:233): premultiplied streams would need the division
   if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated) Fail("premultiplied alpha is not supported yet");
   for (auto& e : f.ec) if (e.dim_shift) Fail("subsampled extra channels are not supported yet");
-  if (PlanColor(f).known_profile < 0)
+  if (PlanColor(f).known_profile < 0 && !PlanColor(f).report_icc)
     Fail("colour encodings other than D65 sRGB / linear sRGB / Display P3 / BT.709 / BT.2020 linear / BT.2020 PQ / gray need an ICC profile, which is not built yet");
   if (f.encoding == 0 && !f.xyb_encoded) Fail("VarDCT frames without XYB are not supported yet");
   if (f.encoding == 1 && f.xyb_encoded) Fail("lossy Modular (XYB) frames are not decoded on the GPU path yet");
-  if (f.encoding == 1 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u)) Fail("extra channels other than alpha are not supported yet");
+  if (f.encoding == 1 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u) + (f.black_index >= 0 ? 1u : 0u))
+    Fail("extra channels other than one alpha and one black (CMYK) channel are not supported yet");
+  if (f.black_index >= 0) {
+    // the reference delivers CMYK as 8-bit samples only (SetCmykImageDataUInt8, Decoder/JxlDecoder.cpp:159-215)
+    if (f.encoding != 1 || f.xyb_encoded || f.ncolor != 3 || f.bits != 8 || f.exp_bits || f.ec[f.black_index].bits != 8 || f.ec[f.black_index].exp_bits)
+      Fail("only 8-bit lossless (Modular, original colour space) CMYK streams are supported");
+  }
+  if (f.encoding == 0 && f.ec.size() > (f.alpha_index >= 0 ? 1u : 0u)) Fail("extra channels other than alpha are not supported in VarDCT frames yet");
   f.single = f.sec_off.size() == 1;
   {
     Bits s(f.cs + f.sec_off[0], f.sec_size[0]);

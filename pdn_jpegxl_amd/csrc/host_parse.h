@@ -50,8 +50,10 @@ struct ExtraChannel { uint32_t type = 0, bits = 8, exp_bits = 0, dim_shift = 0; 
 
 // What the colour encoding of a stream means for the decode (reference: SetProfileFromColorEncoding, Decoder/JxlDecoder.cpp:36-108).
 struct ColorPlan {
-  int known_profile = -1;   // KnownColorProfile the host is told, -1: an encoding the host would need an ICC profile for (not built)
-  int transfer = 1;         // 0 linear, 1 sRGB, 2 BT.709, 3 PQ
+  int known_profile = -1;   // KnownColorProfile the host is told, -1: none of the eight named ones
+  bool report_icc = false;  // the host is handed the embedded ICC profile (setIccProfile) and the samples are in that profile's space
+  int transfer = 1;         // 0 linear, 1 sRGB, 2 BT.709, 3 PQ, 5 the tables of `trc_lut` (an evaluated ICC profile)
+  std::vector<float> trc_lut;   // 3 x kIccInvLut: sqrt(linear) -> encoded
   float from_srgb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // linear sRGB -> linear RGB of the image's primaries (row-major)
 };
 struct ParsedFrame;
@@ -74,6 +76,7 @@ struct ParsedFrame {
   std::vector<ExtraChannel> ec;
   bool xyb_encoded = true;
   ColorInfo color;
+  std::vector<uint8_t> icc;       // the embedded ICC profile (want_icc), decoded
   float intensity_target = 255.f;
   bool have_animation = false, have_timecodes = false;
   float opsin_inv[9], opsin_bias[3], qbias[4];

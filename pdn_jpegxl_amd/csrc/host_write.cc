@@ -1,6 +1,7 @@
 // Host-side writers of the encode path (see host_write.h).  Restates the header syntax of ISO/IEC 18181-1 in the
 // write direction; every field order mirrors the reader in host_parse.cc.
 #include "host_write.h"
+#include "icc.h"
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -402,16 +403,36 @@ void WriteCodestreamHeaders(const EncImageInfo& im, BitWriter& bw) {
   if (im.alpha) bw.Bool(true);                      // the default extra channel: 8-bit unassociated alpha
   bw.Bool(im.xyb);
   // colour encoding: sRGB (or gray with the sRGB transfer curve), D65, perceptual intent (Encoder/JxlEncoder.cpp:269-282)
+  const bool want_icc = im.icc && im.icc_size;
   bw.Bool(false);                                   // not all_default
-  bw.Bool(false);                                   // no ICC
+  bw.Bool(want_icc);
   bw.Enum(im.gray ? 1 : 0);
-  bw.Enum(1);                                       // white point D65
-  if (!im.gray) bw.Enum(1);                         // primaries sRGB
-  bw.Bool(false);                                   // no gamma
-  bw.Enum(13);                                      // transfer function sRGB
-  bw.Enum(0);                                       // rendering intent perceptual
+  if (!want_icc) {
+    bw.Enum(1);                                     // white point D65
+    if (!im.gray) bw.Enum(1);                       // primaries sRGB
+    bw.Bool(false);                                 // no gamma
+    bw.Enum(13);                                    // transfer function sRGB
+    bw.Enum(0);                                     // rendering intent perceptual
+  }
   bw.U64(0);                                        // extensions
   bw.Bool(true);                                    // default transform data
+  if (want_icc) {
+    // the profile: predicted byte stream (icc.cc), 41 contexts on the two previous bytes, ANS
+    std::vector<uint8_t> enc;
+    IccPredict(im.icc, im.icc_size, &enc);
+    bw.U64(enc.size());
+    std::vector<EncToken> tokens(enc.size());
+    std::vector<uint32_t> hist(kIccContexts * kEncAlphabet, 0);
+    for (size_t i = 0; i < enc.size(); i++) {
+      tokens[i] = EncToken{IccContext(i, i > 0 ? enc[i - 1] : 0, i > 1 ? enc[i - 2] : 0), enc[i]};
+      uint32_t tok, nb, bits;
+      HybridEncode(enc[i], &tok, &nb, &bits);
+      hist[tokens[i].ctx * kEncAlphabet + tok]++;
+    }
+    EncCode code;
+    BuildAndWriteCode(hist.data(), kIccContexts, 8, {}, bw, code);
+    WriteTokensHost(tokens, code, bw);
+  }
   bw.AlignByte();
 }
 

@@ -74,6 +74,8 @@ struct EncImageInfo {
   uint32_t xsize = 0, ysize = 0;
   bool gray = false, alpha = false;
   bool xyb = true;       // false: lossless (original colour space, Encoder/JxlEncoder.cpp:214)
+  const uint8_t* icc = nullptr;   // embedded ICC profile (JxlEncoderSetICCProfile, Encoder/JxlEncoder.cpp:258-268) instead of the enum encoding
+  size_t icc_size = 0;
 };
 struct EncFrameInfo {
   uint32_t encoding = 0;           // 0 VarDCT, 1 Modular

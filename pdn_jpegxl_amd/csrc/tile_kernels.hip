@@ -59,9 +59,15 @@ __device__ __forceinline__ float SrgbOetfT(float v) {
   return v <= 0.0031308f ? lin : cur;
 }
 __device__ __forceinline__ float PowT(float a, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * e); }   // a > 0
-// Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ.
-__device__ __forceinline__ float EncodeTransferT(int kind, float v, float pq_scale) {
+// Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ,
+// 5 table (4096 entries over sqrt(linear), clamped to [0, 1]: an evaluated ICC tone curve).
+__device__ __forceinline__ float EncodeTransferT(int kind, float v, float pq_scale, const float* lut = nullptr) {
   if (kind == 0) return v;
+  if (kind == 5) {
+    const float t = __builtin_sqrtf(fminf(fmaxf(v, 0.f), 1.f)) * 4095.0f;
+    const int i = min((int)t, 4094);
+    return lut[i] + (lut[i + 1] - lut[i]) * (t - (float)i);
+  }
   const float a = fabsf(v);
   float r;
   if (kind == 1) r = a <= 0.0031308f ? 12.92f * a : 1.055f * PowT(a, 1.0f / 2.4f) - 0.055f;
@@ -92,7 +98,8 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
     // the common case on its own short path (integer outputs clamp negatives to 0 anyway, so the curve need not be sign-symmetric here)
     r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl);
   } else if (im.to_srgb) {
-    r = EncodeTransferT(im.to_srgb, r, im.pq_scale); g = EncodeTransferT(im.to_srgb, g, im.pq_scale); bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale);
+    r = EncodeTransferT(im.to_srgb, r, im.pq_scale, im.trc_lut); g = EncodeTransferT(im.to_srgb, g, im.pq_scale, im.trc_lut + 4096);
+    bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale, im.trc_lut + 8192);
   }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.out_bits != 8) {   // u16 above 8 bits per sample, f16 / f32 for float samples (Decoder/JxlDecoder.cpp:510-548); `a` is raw bits

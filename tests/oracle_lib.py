@@ -82,7 +82,7 @@ class OracleError(RuntimeError):
 
 def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, seed=1, epf_iters=-1, gaborish=True,
            container=True, adaptive_lf_smoothing=True, lossless_predictor=6, lossless_squeeze=False, num_threads=8, exif=None,
-           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0):
+           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0, icc=None, cmyk=False):
     """px: uint8 array (h, w, nch) with nch in 1..4 (Gray, GrayA, RGB, RGBA); with bits > 8 (up to 16) a uint16 array whose
     samples use the low `bits` bits; with float_samples = 16 / 32 a float16 / float32 array (nominal range [0, 1]).  Returns bytes."""
     L = lib()
@@ -95,6 +95,9 @@ def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, 
     h, w, nch = px.shape
     p = EncodeParams(distance, int(lossless), 7, strategy_mode, fixed_strategy, seed, epf_iters, int(gaborish), int(container),
                      int(adaptive_lf_smoothing), lossless_predictor, int(lossless_squeeze), lossless_tree, num_threads, bits, orientation, float_samples, colour)
+    if icc or cmyk:
+        L.jxo_set_next_icc.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+        L.jxo_set_next_icc(icc, len(icc) if icc else 0, int(cmyk))
     hnd = L.jxo_encode(px.ctypes.data, w, h, nch, C.byref(p), exif, len(exif) if exif else 0, xmp, len(xmp) if xmp else 0)
     if not hnd:
         raise OracleError(L.jxo_last_error().decode())
@@ -111,7 +114,8 @@ _PLANE_DTYPES = {"lf_quant": np.int32, "lf": np.float32, "qcoef": np.int32, "xyb
 
 
 class Decoded:
-    def __init__(self, pixels, w8, h8, planes, exif, xml, epf_iters):
+    def __init__(self, pixels, w8, h8, planes, exif, xml, epf_iters, icc=b"", cmyk=False):
+        self.icc, self.cmyk = icc, cmyk
         self.pixels = pixels
         self.w8, self.h8 = w8, h8
         self.planes = planes
@@ -154,6 +158,11 @@ def decode(data, num_threads=8, want_dump=False):
         exif = bytes(C.string_at(p, n)) if n else b""
         n = L.jxo_image_xml(hnd, C.byref(p))
         xml = bytes(C.string_at(p, n)) if n else b""
-        return Decoded(px, w8.value, h8.value, planes, exif, xml, L.jxo_image_epf_iters(hnd))
+        L.jxo_image_icc.restype = C.c_size_t
+        L.jxo_image_icc.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint8))]
+        L.jxo_image_cmyk.argtypes = [C.c_void_p]
+        n = L.jxo_image_icc(hnd, C.byref(p))
+        icc = bytes(C.string_at(p, n)) if n else b""
+        return Decoded(px, w8.value, h8.value, planes, exif, xml, L.jxo_image_epf_iters(hnd), icc, bool(L.jxo_image_cmyk(hnd)))
     finally:
         L.jxo_image_free(hnd)

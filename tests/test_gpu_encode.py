@@ -122,7 +122,9 @@ def test_single_group_frames_are_valid_streams(oracle):
     assert od.pixels.shape == (120, 200, 4) and (od.pixels[..., 3] == img[..., 3]).all() and psnr(od.pixels[..., :3], img[..., :3]) > 32.0
 
 
-def test_unbuilt_options_fail_loudly():
+def test_profiles_that_need_full_colour_management_fail_loudly_when_saving_lossy():
+    """A lossy save converts the samples to XYB through the profile; a profile this library cannot evaluate is refused, not guessed at
+    (lossless saves carry any profile: tests/test_gpu_icc.py)."""
     bgra = bgra_of(synth(64, 64, 1))
     with pytest.raises(api.JxlError) as e:
         api.save_image(bgra, icc=b"not a real profile")

@@ -90,6 +90,8 @@ struct JxoEncodeParams {
 // an ICC profile to embed, and whether the 4 / 5 channels are CMYK[A].
 static thread_local std::vector<uint8_t> g_next_icc;
 static thread_local bool g_next_cmyk = false;
+static thread_local int g_next_frames = 1;
+void jxo_set_next_animation(int frames) { g_next_frames = frames; }
 void jxo_set_next_icc(const uint8_t* icc, size_t size, int cmyk) {
   g_next_icc.assign(icc ? icc : nullptr, icc ? icc + size : nullptr);
   g_next_cmyk = cmyk != 0;
@@ -129,6 +131,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.colour = ep->colour;
     p.icc.swap(g_next_icc); g_next_icc.clear();
     p.cmyk = g_next_cmyk; g_next_cmyk = false;
+    p.animation_frames = g_next_frames; g_next_frames = 1;
     JxoBytes* b = new JxoBytes();
     b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
     return b;

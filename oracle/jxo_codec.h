@@ -68,10 +68,13 @@ struct EncodeParams {
   int bits = 8;                 // bits per sample signalled in the header (8..16); above 8 the input samples are uint16
   // colour encoding signalled in the header; the pixels handed in are ALREADY in that space (lossy frames are converted to XYB from
   // it).  0: sRGB; 1: Display P3 (sRGB transfer); 2: BT.709 transfer, sRGB primaries; 3: BT.2100 primaries, linear;
-  // 4: BT.2100 primaries, PQ (intensity target 10000); 5: linear sRGB; 6: HLG written to the header only (refusal tests)
+  // 4: BT.2100 primaries, PQ (intensity target 10000); 5: linear sRGB; 6: HLG written to the header only (refusal tests);
+  // 7: Adobe RGB (custom primaries + gamma); 8: DCI-P3 (DCI white, gamma 2.6); 9: sRGB primaries, D50 white, linear
   int colour = 0;
   int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
   std::vector<uint8_t> icc;     // embedded ICC profile instead of the enumerated colour encoding
+  int animation_frames = 1;     // > 1: an animation; frame k > 0 shows the picture rotated by 180 degrees / inverted (any decoder
+                                // that returns something other than the first frame is caught)
   bool cmyk = false;            // lossless only: nch 4 / 5 = C, M, Y, K [, A] as STORED (0 = full ink); K goes to a black extra channel
 };
 

@@ -659,19 +659,18 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     if (dump) for (int c = 0; c < 3; c++) dump->xyb_filtered[c] = img[c].d;
     XybToLinear(m, img);
     const int tfk = TransferKind(m.color);
-    JXO_CHECK(tfk >= 0, "only linear / sRGB / BT.709 / PQ transfer functions are supported yet");
-    JXO_CHECK(m.color.all_default || m.color.white_point == 1, "only the D65 white point is supported yet");
+    JXO_CHECK(tfk >= 0, "only linear / sRGB / BT.709 / PQ / power-law transfer functions are supported");
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
         if (ncolor == 3) {
           for (int c = 0; c < 3; c++) {
             float v = img[c].Row(y)[x];
-            v = EncodeTransfer(tfk, v, m.intensity_target);
+            v = EncodeTransfer(tfk, v, m.intensity_target, PowerLawGamma(m.color));
             put(y, x, c, FloatToOut(v, out.bits_out, out.out_float));
           }
         } else {
           float v = img[1].Row(y)[x];
-          v = EncodeTransfer(tfk, v, m.intensity_target);
+          v = EncodeTransfer(tfk, v, m.intensity_target, PowerLawGamma(m.color));
           put(y, x, 0, FloatToOut(v, out.bits_out, out.out_float));
         }
       }

@@ -257,13 +257,13 @@ struct VarDctEncoder {
         for (int x = 0; x < w; x++) {
           const size_t o = ((size_t)y * w + x) * nch;
           auto F = [&](int c) -> float { return m.bits == 32 ? ((const float*)px)[o + c] : HalfBitsToFloat(((const uint16_t*)px)[o + c]); };
-          for (int c = 0; c < 3; c++) img[c].Row(y)[x] = DecodeTransfer(tfk, F(ncolor == 3 ? c : 0), m.intensity_target);
+          for (int c = 0; c < 3; c++) img[c].Row(y)[x] = DecodeTransfer(tfk, F(ncolor == 3 ? c : 0), m.intensity_target, PowerLawGamma(m.color));
           if (has_alpha) alpha[(size_t)y * w + x] = m.bits == 32 ? ((const int32_t*)px)[o + ncolor] : (int32_t)((const uint16_t*)px)[o + ncolor];
         }
     } else {
     const uint32_t maxv = (1u << m.bits) - 1;
     std::vector<float> lut((size_t)maxv + 1);
-    for (uint32_t i = 0; i <= maxv; i++) lut[i] = DecodeTransfer(tfk, (float)i / (float)maxv, m.intensity_target);
+    for (uint32_t i = 0; i <= maxv; i++) lut[i] = DecodeTransfer(tfk, (float)i / (float)maxv, m.intensity_target, PowerLawGamma(m.color));
     const uint16_t* px16 = (const uint16_t*)px;   // samples above 8 bits arrive as uint16
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) {
@@ -276,14 +276,15 @@ struct VarDctEncoder {
     {
       // linear RGB of the image's primaries, relative to the intensity target -> linear sRGB relative to 255 nits (what XYB is built on)
       double conv[9], inv[9];
-      JXO_CHECK(MatrixFromSrgb(ncolor == 3 ? m.color.primaries : 1, conv), "primaries");
+      if (ncolor == 3) JXO_CHECK(MatrixFromSrgbGeneral(m.color, conv), "primaries / white point");
+      else MatrixFromSrgb(1, conv);
       const double d = conv[0] * (conv[4] * conv[8] - conv[5] * conv[7]) - conv[1] * (conv[3] * conv[8] - conv[5] * conv[6]) +
                        conv[2] * (conv[3] * conv[7] - conv[4] * conv[6]);
       inv[0] = (conv[4] * conv[8] - conv[5] * conv[7]) / d; inv[1] = (conv[2] * conv[7] - conv[1] * conv[8]) / d; inv[2] = (conv[1] * conv[5] - conv[2] * conv[4]) / d;
       inv[3] = (conv[5] * conv[6] - conv[3] * conv[8]) / d; inv[4] = (conv[0] * conv[8] - conv[2] * conv[6]) / d; inv[5] = (conv[2] * conv[3] - conv[0] * conv[5]) / d;
       inv[6] = (conv[3] * conv[7] - conv[4] * conv[6]) / d; inv[7] = (conv[1] * conv[6] - conv[0] * conv[7]) / d; inv[8] = (conv[0] * conv[4] - conv[1] * conv[3]) / d;
       const double sc = m.intensity_target / 255.0;
-      const bool ident = m.color.primaries == 1 && sc == 1.0;
+      const bool ident = m.color.primaries == 1 && m.color.white_point == 1 && sc == 1.0;
       if (!ident)
         for (size_t i = 0; i < img[0].d.size(); i++) {
           const double r = img[0].d[i], g = img[1].d[i], b = img[2].d[i];
@@ -638,6 +639,13 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
     case 4: m.color.primaries = 9; m.color.tf = 16; m.intensity_target = 10000.f; break;
     case 5: m.color.tf = 8; break;
     case 6: m.color.tf = 18; break;   // HLG in the header only (test stream for decoders that must refuse it)
+    case 7:   // Adobe RGB (1998): custom primaries, D65, gamma 563 / 256
+      m.color.primaries = 2; m.color.have_gamma = true; m.color.gamma = 4547069;
+      m.color.custom_xy[1][0] = 640000; m.color.custom_xy[1][1] = 330000; m.color.custom_xy[2][0] = 210000; m.color.custom_xy[2][1] = 710000;
+      m.color.custom_xy[3][0] = 150000; m.color.custom_xy[3][1] = 60000;
+      break;
+    case 8: m.color.white_point = 11; m.color.primaries = 11; m.color.tf = 17; break;   // DCI-P3: DCI white, P3 primaries, gamma 2.6
+    case 9: m.color.white_point = 2; m.color.custom_xy[0][0] = 345700; m.color.custom_xy[0][1] = 358500; m.color.tf = 8; break;   // linear, D50 white
     default: JXO_CHECK(false, "unknown colour option");
   }
   if (nch < 3) m.color.primaries = 1;   // gray: no primaries
@@ -652,25 +660,41 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
     m.ec.push_back(ExtraChannelInfo()); m.ec.back().type = 4; m.ec.back().bits = m.bits;
     if (nch == 5) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; }
   } else if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; }
-  FrameHeader f;
-  f.ec_upsampling.assign(m.ec.size(), 1);
+  m.have_animation = p.animation_frames > 1;
   std::vector<uint8_t> frame;
-  if (p.lossless) {
-    frame = EncodeLosslessFrame(m, f, px, nch, p);
-  } else {
-    f.encoding = 0;
-    f.lf.gab = p.gaborish;
-    int iters = p.epf_iters;
-    if (iters < 0) {
-      iters = 0;
-      for (float t : {0.7f, 1.5f, 4.0f}) if (p.distance >= t) iters++;
+  const size_t bytes_per_px = (size_t)nch * (m.bits > 16 ? 4 : (m.bits > 8 ? 2 : 1));
+  for (int k = 0; k < std::max(1, p.animation_frames); k++) {
+    // later frames of an animation: the same picture upside down and mirrored
+    std::vector<uint8_t> other;
+    const uint8_t* src = px;
+    if (k > 0) {
+      other.resize((size_t)w * h * bytes_per_px);
+      for (size_t i = 0; i < (size_t)w * h; i++) memcpy(&other[i * bytes_per_px], px + ((size_t)w * h - 1 - i) * bytes_per_px, bytes_per_px);
+      src = other.data();
     }
-    f.lf.epf_iters = iters;
-    if (!p.adaptive_lf_smoothing) f.flags |= FrameHeader::kSkipAdaptiveLfSmoothing;
-    VarDctEncoder enc(p);
-    enc.m = m;
-    enc.f = f;
-    frame = enc.Encode(px, nch);
+    FrameHeader f;
+    f.ec_upsampling.assign(m.ec.size(), 1);
+    f.is_last = k + 1 == std::max(1, p.animation_frames);
+    f.duration = m.have_animation ? 10 : 0;
+    std::vector<uint8_t> one;
+    if (p.lossless) {
+      one = EncodeLosslessFrame(m, f, src, nch, p);
+    } else {
+      f.encoding = 0;
+      f.lf.gab = p.gaborish;
+      int iters = p.epf_iters;
+      if (iters < 0) {
+        iters = 0;
+        for (float t : {0.7f, 1.5f, 4.0f}) if (p.distance >= t) iters++;
+      }
+      f.lf.epf_iters = iters;
+      if (!p.adaptive_lf_smoothing) f.flags |= FrameHeader::kSkipAdaptiveLfSmoothing;
+      VarDctEncoder enc(p);
+      enc.m = m;
+      enc.f = f;
+      one = enc.Encode(src, nch);
+    }
+    frame.insert(frame.end(), one.begin(), one.end());
   }
   BitWriter bw;
   bw.Write(8, 0xFF);

@@ -88,13 +88,17 @@ static void WriteColorEncoding(BitWriter& bw, const ColorEncoding& c) {
   bw.Bool(c.want_icc);
   bw.Enum(c.color_space);
   if (c.want_icc) return;
+  auto write_xy = [&](int32_t v) {
+    const uint32_t u = v >= 0 ? (uint32_t)v << 1 : (((uint32_t)(-(int64_t)v)) << 1) - 1;
+    bw.U32(Bits(19), BitsOff(19, 524288), BitsOff(20, 1048576), BitsOff(21, 2097152), u);
+  };
   if (c.color_space != 2) {
-    JXO_CHECK(c.white_point != 2, "custom white point not written");
     bw.Enum(c.white_point);
+    if (c.white_point == 2) { write_xy(c.custom_xy[0][0]); write_xy(c.custom_xy[0][1]); }
   }
   if (c.color_space != 2 && c.color_space != 1) {
-    JXO_CHECK(c.primaries != 2, "custom primaries not written");
     bw.Enum(c.primaries);
+    if (c.primaries == 2) for (int i = 1; i < 4; i++) { write_xy(c.custom_xy[i][0]); write_xy(c.custom_xy[i][1]); }
   }
   if (c.color_space != 2) {
     bw.Bool(c.have_gamma);
@@ -194,13 +198,19 @@ void WriteImageMetadata(BitWriter& bw, const ImageMetadata& m) {
                      m.color.all_default && m.intensity_target == 255.f && !m.have_animation;
   bw.Bool(all_default);
   if (!all_default) {
-    bool extra = m.orientation != 1 || m.intensity_target != 255.f;
+    bool extra = m.orientation != 1 || m.intensity_target != 255.f || m.have_animation;
     bw.Bool(extra);
     if (extra) {
       bw.Write(3, m.orientation - 1);
       bw.Bool(false);  // intrinsic size
       bw.Bool(false);  // preview
-      bw.Bool(false);  // animation
+      bw.Bool(m.have_animation);
+      if (m.have_animation) {
+        bw.U32(Val(100), Val(1000), BitsOff(10, 1), BitsOff(30, 1), 100);   // ticks per second: 100 / 1
+        bw.U32(Val(1), Val(1001), BitsOff(8, 1), BitsOff(10, 1), 1);
+        bw.U32(Val(0), Bits(3), Bits(16), Bits(32), 0);                      // loops forever
+        bw.Bool(false);                                                       // no timecodes
+      }
     }
     WriteBitDepth(bw, m.bits, m.exp_bits);
     bw.Bool(m.modular_16bit);
@@ -372,7 +382,8 @@ void WriteFrameHeader(BitWriter& bw, const ImageMetadata& m, const FrameHeader& 
                      f.name.empty() && lf_default && !m.have_animation;
   bw.Bool(all_default);
   if (all_default) return;
-  JXO_CHECK(f.frame_type == 0 && !f.have_crop && f.num_passes == 1 && f.is_last && f.upsampling == 1, "oracle encoder writes single regular frames");
+  JXO_CHECK(f.frame_type == 0 && !f.have_crop && f.num_passes == 1 && f.upsampling == 1 && (f.is_last || m.have_animation),
+            "oracle encoder writes regular full frames (several only as an animation)");
   bw.Write(2, f.frame_type);
   bw.Write(1, f.encoding);
   bw.U64(f.flags);
@@ -389,7 +400,12 @@ void WriteFrameHeader(BitWriter& bw, const ImageMetadata& m, const FrameHeader& 
   // blending info (replace), full frame => no source field
   bw.U32(Val(0), Val(1), Val(2), BitsOff(2, 3), 0);
   for (size_t i = 0; i < m.ec.size(); i++) bw.U32(Val(0), Val(1), Val(2), BitsOff(2, 3), 0);
-  bw.Bool(true);  // is_last
+  if (m.have_animation) bw.U32(Val(0), Val(1), Bits(8), Bits(32), f.duration);
+  bw.Bool(f.is_last);
+  if (!f.is_last) {
+    bw.Write(2, 0);   // save_as_reference 0; with a duration and no reference slot nothing more is signalled
+    JXO_CHECK(f.duration > 0, "a frame that is not the last needs a duration here");
+  }
   bw.U32(Val(0), Bits(4), BitsOff(5, 16), BitsOff(10, 48), (uint32_t)f.name.size());
   for (char ch : f.name) bw.Write(8, (uint8_t)ch);
   bw.Bool(lf_default);

@@ -818,8 +818,7 @@ void Epf(Plane xyb[3], const LoopFilter& lf, const Plane& inv_sigma) {
 void XybToLinear(const ImageMetadata& m, Plane xyb[3]) {
   // linear RGB of the image's own primaries: the change of primaries is folded into the inverse opsin matrix
   double conv[9];
-  const uint32_t prim = m.color.all_default ? 1 : m.color.primaries;
-  JXO_CHECK(m.color.color_space == 1 || MatrixFromSrgb(prim, conv), "only sRGB / P3 / BT.2100 primaries are supported yet");
+  JXO_CHECK(MatrixFromSrgbGeneral(m.color, conv), "this combination of primaries and white point is not supported");
   if (m.color.color_space == 1) MatrixFromSrgb(1, conv);
   float inv[9];
   for (int r = 0; r < 3; r++)
@@ -870,22 +869,29 @@ float SrgbToLinear(float v) {
   return std::copysign(r, v);
 }
 
-int TransferKind(const ColorEncoding& c) {
+double PowerLawGamma(const ColorEncoding& c) {
+  if (c.all_default) return 0.0;
+  if (c.have_gamma) return c.gamma * 1e-7;
+  return c.tf == 17 ? 1.0 / 2.6 : 0.0;
+}
+int TransferKind(const ColorEncoding& c) {   // 4: pure power law (PowerLawGamma)
   if (c.all_default) return 1;
-  if (c.have_gamma) return -1;
+  if (c.have_gamma) return 4;
   switch (c.tf) {
     case 8: return 0;
     case 13: return 1;
     case 1: return 2;
     case 16: return 3;
+    case 17: return 4;
     default: return -1;
   }
 }
 static const float kPqM1 = 0.1593017578125f, kPqM2 = 78.84375f, kPqC1 = 0.8359375f, kPqC2 = 18.8515625f, kPqC3 = 18.6875f;
-float EncodeTransfer(int kind, float v, float intensity_target) {
+float EncodeTransfer(int kind, float v, float intensity_target, double gamma) {
   const float a = std::fabs(v);
   float r;
   switch (kind) {
+    case 4: r = (float)std::pow((double)a, gamma); break;
     case 1: return LinearToSrgb(v);
     case 2: r = a < 0.018f ? 4.5f * a : 1.099f * std::pow(a, 0.45f) - 0.099f; break;
     case 3: {
@@ -898,10 +904,11 @@ float EncodeTransfer(int kind, float v, float intensity_target) {
   }
   return std::copysign(r, v);
 }
-float DecodeTransfer(int kind, float e, float intensity_target) {
+float DecodeTransfer(int kind, float e, float intensity_target, double gamma) {
   const float a = std::fabs(e);
   float r;
   switch (kind) {
+    case 4: r = (float)std::pow((double)a, 1.0 / gamma); break;
     case 1: return SrgbToLinear(e);
     case 2: r = a < 0.081f ? a / 4.5f : std::pow((a + 0.099f) / 1.099f, 1.0f / 0.45f); break;
     case 3: {
@@ -947,6 +954,56 @@ bool MatrixFromSrgb(uint32_t primaries, double out[9]) {
   Inv3(mt, mti);
   for (int r = 0; r < 3; r++)
     for (int c = 0; c < 3; c++) out[r * 3 + c] = mti[r * 3] * ms[c] + mti[r * 3 + 1] * ms[3 + c] + mti[r * 3 + 2] * ms[6 + c];
+  return true;
+}
+
+// RGB (chromaticities + white) -> XYZ relative to D50: colorant matrix scaled to the white, then the von Kries step in Bradford's cone space
+static void ToXyzD50(const double prim[3][2], const double white[2], double out[9]) {
+  auto XYZ = [](const double* xy, double* v) { v[0] = xy[0] / xy[1]; v[1] = 1.0; v[2] = (1.0 - xy[0] - xy[1]) / xy[1]; };
+  double P[9], Pi[9], W[3];
+  for (int c = 0; c < 3; c++) { double v[3]; XYZ(prim[c], v); P[c] = v[0]; P[3 + c] = v[1]; P[6 + c] = v[2]; }
+  XYZ(white, W);
+  Inv3(P, Pi);
+  double M[9];
+  for (int c = 0; c < 3; c++) {
+    const double s = Pi[c * 3] * W[0] + Pi[c * 3 + 1] * W[1] + Pi[c * 3 + 2] * W[2];
+    for (int r = 0; r < 3; r++) M[r * 3 + c] = P[r * 3 + c] * s;
+  }
+  static const double kCone[9] = {0.8951, 0.2664, -0.1614, -0.7502, 1.7135, 0.0367, 0.0389, -0.0685, 1.0296};
+  const double D50[3] = {0.96422, 1.0, 0.82521};
+  double cw[3], cd[3], ci[9], diag[9], ad[9];
+  for (int r = 0; r < 3; r++) {
+    cw[r] = kCone[r * 3] * W[0] + kCone[r * 3 + 1] * W[1] + kCone[r * 3 + 2] * W[2];
+    cd[r] = kCone[r * 3] * D50[0] + kCone[r * 3 + 1] * D50[1] + kCone[r * 3 + 2] * D50[2];
+  }
+  Inv3(kCone, ci);
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) diag[r * 3 + c] = kCone[r * 3 + c] * cd[r] / cw[r];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) ad[r * 3 + c] = ci[r * 3] * diag[c] + ci[r * 3 + 1] * diag[3 + c] + ci[r * 3 + 2] * diag[6 + c];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out[r * 3 + c] = ad[r * 3] * M[c] + ad[r * 3 + 1] * M[3 + c] + ad[r * 3 + 2] * M[6 + c];
+}
+
+bool MatrixFromSrgbGeneral(const ColorEncoding& c, double out[9]) {
+  if (c.all_default) return MatrixFromSrgb(1, out);
+  double white[2] = {0.3127, 0.3290};
+  if (c.white_point == 2) { white[0] = c.custom_xy[0][0] * 1e-6; white[1] = c.custom_xy[0][1] * 1e-6; }
+  else if (c.white_point == 10) white[0] = white[1] = 1.0 / 3;
+  else if (c.white_point == 11) { white[0] = 0.314; white[1] = 0.351; }
+  else if (c.white_point != 1) return false;
+  static const double kSrgb[3][2] = {{0.639998686, 0.330010138}, {0.300003784, 0.600003357}, {0.150002046, 0.059997204}};
+  static const double kP3[3][2] = {{0.680, 0.320}, {0.265, 0.690}, {0.150, 0.060}};
+  static const double k2100[3][2] = {{0.708, 0.292}, {0.170, 0.797}, {0.131, 0.046}};
+  double prim[3][2];
+  if (c.color_space == 1 || c.primaries == 1) memcpy(prim, kSrgb, sizeof(prim));
+  else if (c.primaries == 11) memcpy(prim, kP3, sizeof(prim));
+  else if (c.primaries == 9) memcpy(prim, k2100, sizeof(prim));
+  else if (c.primaries == 2) for (int i = 0; i < 3; i++) { prim[i][0] = c.custom_xy[i + 1][0] * 1e-6; prim[i][1] = c.custom_xy[i + 1][1] * 1e-6; }
+  else return false;
+  const double d65[2] = {0.3127, 0.3290};
+  double s[9], t[9], ti[9];
+  ToXyzD50(kSrgb, d65, s);
+  ToXyzD50(prim, white, t);
+  Inv3(t, ti);
+  for (int r = 0; r < 3; r++) for (int k = 0; k < 3; k++) out[r * 3 + k] = ti[r * 3] * s[k] + ti[r * 3 + 1] * s[3 + k] + ti[r * 3 + 2] * s[6 + k];
   return true;
 }
 

@@ -72,10 +72,15 @@ float SrgbToLinear(float v);
 // BT.2100, transfer linear / sRGB / BT.709 / PQ.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ; -1: not one of those.
 int TransferKind(const ColorEncoding& c);
 // Encoded value from display-linear (sign-symmetric like the reference's library); PQ takes the image's intensity target.
-float EncodeTransfer(int kind, float v, float intensity_target);
-float DecodeTransfer(int kind, float e, float intensity_target);
+float EncodeTransfer(int kind, float v, float intensity_target, double gamma = 1.0);
+float DecodeTransfer(int kind, float e, float intensity_target, double gamma = 1.0);
 // 3x3 (row-major) linear sRGB -> linear RGB of the primaries (1 sRGB: identity, 9 BT.2100, 11 P3); false: other primaries.
 bool MatrixFromSrgb(uint32_t primaries, double out[9]);
+// The same for any enumerated encoding (custom chromaticities, white points D65 / E / DCI / custom): through XYZ adapted to D50 with
+// the Bradford transform, as the decoder library behind the reference builds its output matrices.  false: not expressible.
+bool MatrixFromSrgbGeneral(const ColorEncoding& c, double out[9]);
+// Exponent of pure power-law transfer functions (encoded = linear ^ gamma): explicit gamma and DCI (1 / 2.6); 0 otherwise.
+double PowerLawGamma(const ColorEncoding& c);
 
 // Block-context map (HfBlockContext) of LfGlobal.
 struct BlockCtxMap {

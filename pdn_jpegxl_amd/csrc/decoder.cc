@@ -1244,7 +1244,8 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
     {
       const ColorPlan plan = PlanColor(f);
       if (plan.report_icc) {   // the target-data profile is the embedded ICC profile (:652-682)
-        if (!f.icc.empty() && !cb->setIccProfile(f.icc.data(), f.icc.size())) return DecoderStatus_CreateMetadataError;
+        const std::vector<uint8_t>& prof = f.icc.empty() ? plan.icc_out : f.icc;   // embedded, or synthesised for the enumerated encoding
+        if (!prof.empty() && !cb->setIccProfile(const_cast<uint8_t*>(prof.data()), prof.size())) return DecoderStatus_CreateMetadataError;
       } else if (plan.known_profile < 0) {
         SetErr(err, "This colour encoding needs a synthesised ICC profile, which the GPU path does not build yet.");
         return DecoderStatus_DecodeError;

@@ -503,9 +503,15 @@ void ReadImageHeader(Bits& r, ParsedFrame& f) {
       c.want_icc = r.b();
       c.color_space = r.Enum();
       if (!c.want_icc) {
-        auto xy = [&]() { r.U32(B(19), B(19, 524288), B(20, 1048576), B(21, 2097152)); };
-        if (c.color_space != 2) { c.white_point = r.Enum(); if (c.white_point == 2) { xy(); xy(); } }
-        if (c.color_space != 2 && c.color_space != 1) { c.primaries = r.Enum(); if (c.primaries == 2) for (int i = 0; i < 6; i++) xy(); }
+        auto xy = [&]() {
+          const uint32_t u = r.U32(B(19), B(19, 524288), B(20, 1048576), B(21, 2097152));
+          return (double)((int32_t)(u >> 1) ^ -(int32_t)(u & 1)) * 1e-6;
+        };
+        if (c.color_space != 2) { c.white_point = r.Enum(); if (c.white_point == 2) { c.white_xy[0] = xy(); c.white_xy[1] = xy(); } }
+        if (c.color_space != 2 && c.color_space != 1) {
+          c.primaries = r.Enum();
+          if (c.primaries == 2) for (int i = 0; i < 3; i++) { c.prim_xy[i][0] = xy(); c.prim_xy[i][1] = xy(); }
+        }
         if (c.color_space != 2) { c.have_gamma = r.b(); if (c.have_gamma) c.gamma = r.u(24); else c.tf = r.Enum(); }
         c.rendering_intent = r.Enum();
       }
@@ -1252,8 +1258,51 @@ ColorPlan PlanColor(const ParsedFrame& f) {
     p.known_profile = cs == 1 ? KnownColorProfile_GraySrgbTRC : KnownColorProfile_Srgb;
     return p;
   }
-  if (c.have_gamma || wp != 1) return p;
   p.transfer = tf == 8 ? 0 : (tf == 13 ? 1 : (tf == 1 ? 2 : (tf == 16 ? 3 : -1)));
+  const bool named = !c.have_gamma && wp == 1 &&
+                     ((cs == 0 && ((tf == 8 && (pr == 1 || pr == 9)) || (tf == 13 && (pr == 1 || pr == 11)) || (tf == 1 && pr == 1) || (tf == 16 && pr == 9))) ||
+                      (cs == 1 && (tf == 8 || tf == 13)));
+  if (!named) {
+    // Not one of the host's eight named profiles (Decoder/JxlDecoder.cpp:36-108): the reference then asks its decoder library for an ICC
+    // profile of the target data (:652-682).  Spaces given by chromaticities + a power / sRGB / BT.709 / linear curve are decoded into
+    // and described by a synthesised matrix / TRC profile; PQ and HLG outside BT.2100-PQ, "unknown" curves and XYB-as-output are not.
+    p.known_profile = -1;
+    if (cs != 0 && cs != 1) return p;
+    double white[2] = {0.3127, 0.3290}, prim[3][2] = {{0.639998686, 0.330010138}, {0.300003784, 0.600003357}, {0.150002046, 0.059997204}};
+    if (wp == 2) { white[0] = c.white_xy[0]; white[1] = c.white_xy[1]; }
+    else if (wp == 10) { white[0] = white[1] = 1.0 / 3; }
+    else if (wp == 11) { white[0] = 0.314; white[1] = 0.351; }
+    else if (wp != 1) return p;
+    if (cs == 0) {
+      static const double kP3[3][2] = {{0.680, 0.320}, {0.265, 0.690}, {0.150, 0.060}}, k2100[3][2] = {{0.708, 0.292}, {0.170, 0.797}, {0.131, 0.046}};
+      if (pr == 2) memcpy(prim, c.prim_xy, sizeof(prim));
+      else if (pr == 11) memcpy(prim, kP3, sizeof(prim));
+      else if (pr == 9) memcpy(prim, k2100, sizeof(prim));
+      else if (pr != 1) return p;
+    }
+    if (white[1] < 1e-3 || prim[0][1] < 1e-3 || prim[1][1] < 1e-3 || prim[2][1] < 1e-3) return p;
+    IccCurveSpec curve;
+    if (c.have_gamma) { curve.kind = 4; curve.gamma = c.gamma * 1e-7; if (!(curve.gamma > 0.01 && curve.gamma <= 1.0)) return p; }
+    else if (tf == 8) curve.kind = 0;
+    else if (tf == 13) curve.kind = 1;
+    else if (tf == 1) curve.kind = 2;
+    else if (tf == 17) { curve.kind = 4; curve.gamma = 1 / 2.6; }
+    else return p;
+    double m[9];
+    if (cs == 0) { if (!MatrixFromLinearSrgb(prim, white, m)) return p; for (int k = 0; k < 9; k++) p.from_srgb[k] = (float)m[k]; }
+    if (curve.kind == 4) {   // power curve: as a table over sqrt(linear), like the evaluated ICC curves
+      p.transfer = 5;
+      p.trc_lut.resize(3 * (size_t)kIccInvLut);
+      for (int i = 0; i < kIccInvLut; i++) {
+        const double t = (double)i / (kIccInvLut - 1);
+        const float v = (float)std::pow(t * t, curve.gamma);
+        p.trc_lut[i] = p.trc_lut[kIccInvLut + i] = p.trc_lut[2 * kIccInvLut + i] = v;
+      }
+    } else p.transfer = curve.kind;
+    p.report_icc = true;
+    p.icc_out = IccSynthesize(cs == 1, prim, white, curve, c.all_default ? 1 : c.rendering_intent);
+    return p;
+  }
   if (cs == 0) {   // RGB, D65 (Decoder/JxlDecoder.cpp:42-88)
     if (tf == 8) p.known_profile = pr == 1 ? KnownColorProfile_LinearSrgb : (pr == 9 ? KnownColorProfile_Rec2020Linear : -1);
     else if (tf == 13) p.known_profile = pr == 1 ? KnownColorProfile_Srgb : (pr == 11 ? KnownColorProfile_DisplayP3 : -1);

@@ -44,6 +44,8 @@ struct ColorInfo {
   uint32_t color_space = 0, white_point = 1, primaries = 1, tf = 13, rendering_intent = 1;
   bool have_gamma = false;
   uint32_t gamma = 0;
+  double white_xy[2] = {0.3127, 0.3290};   // custom white point / primaries as signalled (white_point == 2 / primaries == 2)
+  double prim_xy[3][2] = {{0.64, 0.33}, {0.30, 0.60}, {0.15, 0.06}};
 };
 
 struct ExtraChannel { uint32_t type = 0, bits = 8, exp_bits = 0, dim_shift = 0; bool alpha_associated = false; };
@@ -54,6 +56,7 @@ struct ColorPlan {
   bool report_icc = false;  // the host is handed the embedded ICC profile (setIccProfile) and the samples are in that profile's space
   int transfer = 1;         // 0 linear, 1 sRGB, 2 BT.709, 3 PQ, 5 the tables of `trc_lut` (an evaluated ICC profile)
   std::vector<float> trc_lut;   // 3 x kIccInvLut: sqrt(linear) -> encoded
+  std::vector<uint8_t> icc_out; // report_icc without an embedded profile: the profile synthesised for the enumerated encoding
   float from_srgb[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // linear sRGB -> linear RGB of the image's primaries (row-major)
 };
 struct ParsedFrame;

@@ -401,4 +401,122 @@ bool IccBuildModel(const uint8_t* icc, size_t size, IccModel* m) {
   return Invert3(m->from_linear_srgb, m->to_linear_srgb);
 }
 
+// ---------------------------------------------------------------------------------------------- spaces from chromaticities
+namespace {
+const double kBradford[9] = {0.8951, 0.2664, -0.1614, -0.7502, 1.7135, 0.0367, 0.0389, -0.0685, 1.0296};
+void XyToXyz(const double xy[2], double out[3]) { out[0] = xy[0] / xy[1]; out[1] = 1.0; out[2] = (1.0 - xy[0] - xy[1]) / xy[1]; }
+// adaptation of white `w` (XYZ) to D50 in the Bradford cone space
+void AdaptToD50(const double w[3], double out[9]) {
+  const double d50[3] = {0.96422, 1.0, 0.82521};
+  double lw[3], ld[3], bi[9];
+  for (int r = 0; r < 3; r++) {
+    lw[r] = kBradford[r * 3] * w[0] + kBradford[r * 3 + 1] * w[1] + kBradford[r * 3 + 2] * w[2];
+    ld[r] = kBradford[r * 3] * d50[0] + kBradford[r * 3 + 1] * d50[1] + kBradford[r * 3 + 2] * d50[2];
+  }
+  Invert3(kBradford, bi);
+  double scaled[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) scaled[r * 3 + c] = kBradford[r * 3 + c] * (ld[r] / lw[r]);
+  Mul3(bi, scaled, out);
+}
+void PutS15(double v, std::vector<uint8_t>* out) { PutU32((uint32_t)(int32_t)std::lrint(v * 65536.0), out); }
+}  // namespace
+
+void PrimariesToXyzD50(const double prim_xy[3][2], const double white_xy[2], double out[9]) {
+  double p[9], pi[9], w[3];
+  for (int c = 0; c < 3; c++) { double t[3]; XyToXyz(prim_xy[c], t); p[c] = t[0]; p[3 + c] = t[1]; p[6 + c] = t[2]; }
+  XyToXyz(white_xy, w);
+  Invert3(p, pi);
+  double m[9];
+  for (int c = 0; c < 3; c++) {
+    const double sc = pi[c * 3] * w[0] + pi[c * 3 + 1] * w[1] + pi[c * 3 + 2] * w[2];
+    for (int r = 0; r < 3; r++) m[r * 3 + c] = p[r * 3 + c] * sc;
+  }
+  double ad[9];
+  AdaptToD50(w, ad);
+  Mul3(ad, m, out);
+}
+
+bool MatrixFromLinearSrgb(const double prim_xy[3][2], const double white_xy[2], double out[9]) {
+  static const double kSrgb[3][2] = {{0.639998686, 0.330010138}, {0.300003784, 0.600003357}, {0.150002046, 0.059997204}};
+  static const double kD65[2] = {0.3127, 0.3290};
+  double s[9], t[9], ti[9];
+  PrimariesToXyzD50(kSrgb, kD65, s);
+  PrimariesToXyzD50(prim_xy, white_xy, t);
+  if (!Invert3(t, ti)) return false;
+  Mul3(ti, s, out);
+  return true;
+}
+
+std::vector<uint8_t> IccSynthesize(bool gray, const double prim_xy[3][2], const double white_xy[2], const IccCurveSpec& curve, uint32_t rendering_intent) {
+  auto mluc = [](const char* text) {
+    std::vector<uint8_t> t;
+    PutTag("mluc", &t); PutU32(0, &t); PutU32(1, &t); PutU32(12, &t); PutTag("enUS", &t);
+    const size_t n = strlen(text);
+    PutU32((uint32_t)(2 * n), &t); PutU32(28, &t);
+    for (size_t i = 0; i < n; i++) { t.push_back(0); t.push_back((uint8_t)text[i]); }
+    return t;
+  };
+  auto xyz = [](const double v[3]) {
+    std::vector<uint8_t> t;
+    PutTag("XYZ ", &t); PutU32(0, &t);
+    for (int i = 0; i < 3; i++) PutS15(v[i], &t);
+    return t;
+  };
+  // tone curve as a parametric curve (encoded -> linear)
+  std::vector<uint8_t> trc;
+  PutTag("para", &trc); PutU32(0, &trc);
+  if (curve.kind == 1 || curve.kind == 2) {
+    trc.push_back(0); trc.push_back(3); trc.push_back(0); trc.push_back(0);
+    const double p1[5] = {2.4, 1 / 1.055, 0.055 / 1.055, 1 / 12.92, 0.04045}, p2[5] = {1 / 0.45, 1 / 1.099, 0.099 / 1.099, 1 / 4.5, 0.081};
+    for (int i = 0; i < 5; i++) PutS15(curve.kind == 1 ? p1[i] : p2[i], &trc);
+  } else {
+    trc.push_back(0); trc.push_back(0); trc.push_back(0); trc.push_back(0);
+    PutS15(curve.kind == 0 ? 1.0 : 1.0 / curve.gamma, &trc);
+  }
+  double w[3], ad[9], m[9];
+  XyToXyz(white_xy, w);
+  AdaptToD50(w, ad);
+  std::vector<uint8_t> chad;
+  PutTag("sf32", &chad); PutU32(0, &chad);
+  for (int i = 0; i < 9; i++) PutS15(ad[i], &chad);
+  const double d50[3] = {0.9642, 1.0, 0.8249};
+  std::vector<std::pair<const char*, std::vector<uint8_t>>> tags;
+  tags.push_back({"desc", mluc(gray ? "JPEG XL gray (synthesised)" : "JPEG XL RGB (synthesised)")});
+  tags.push_back({"cprt", mluc("CC0")});
+  tags.push_back({"wtpt", xyz(d50)});
+  tags.push_back({"chad", chad});
+  if (gray) tags.push_back({"kTRC", trc});
+  else {
+    PrimariesToXyzD50(prim_xy, white_xy, m);
+    const char* const kC[3] = {"rXYZ", "gXYZ", "bXYZ"};
+    for (int c = 0; c < 3; c++) { const double col[3] = {m[c], m[3 + c], m[6 + c]}; tags.push_back({kC[c], xyz(col)}); }
+    tags.push_back({"rTRC", trc});
+  }
+  const size_t nshared = gray ? 0 : 2;   // gTRC, bTRC point at rTRC
+  const size_t ntags = tags.size() + nshared;
+  std::vector<uint8_t> table, data;
+  PutU32((uint32_t)ntags, &table);
+  size_t off = 128 + 4 + 12 * ntags, trc_off = 0, trc_len = 0;
+  for (auto& t : tags) {
+    PutTag(t.first, &table); PutU32((uint32_t)(off + data.size()), &table); PutU32((uint32_t)t.second.size(), &table);
+    if (!strcmp(t.first, "rTRC")) { trc_off = off + data.size(); trc_len = t.second.size(); }
+    data.insert(data.end(), t.second.begin(), t.second.end());
+    while (data.size() & 3) data.push_back(0);
+  }
+  if (!gray) for (const char* n : {"gTRC", "bTRC"}) { PutTag(n, &table); PutU32((uint32_t)trc_off, &table); PutU32((uint32_t)trc_len, &table); }
+  std::vector<uint8_t> out;
+  PutU32((uint32_t)(128 + table.size() + data.size()), &out);
+  PutTag("jxl ", &out); PutU32(0x04400000, &out); PutTag("mntr", &out); PutTag(gray ? "GRAY" : "RGB ", &out); PutTag("XYZ ", &out);
+  const uint8_t date[12] = {7, 234, 0, 1, 0, 1, 0, 0, 0, 0, 0, 0};
+  out.insert(out.end(), date, date + 12);
+  PutTag("acsp", &out); PutTag("APPL", &out); PutU32(0, &out); PutU32(0, &out); PutU32(0, &out); PutU32(0, &out); PutU32(0, &out);
+  PutU32(rendering_intent & 3, &out);
+  for (int i = 0; i < 3; i++) PutS15(d50[i], &out);
+  PutTag("jxl ", &out);
+  out.resize(128, 0);
+  out.insert(out.end(), table.begin(), table.end());
+  out.insert(out.end(), data.begin(), data.end());
+  return out;
+}
+
 }  // namespace jxlhip

@@ -39,6 +39,19 @@ struct IccModel {
 constexpr int kIccInvLut = 4096;
 bool IccBuildModel(const uint8_t* icc, size_t size, IccModel* model);
 
+// Colour spaces given by chromaticities and a simple tone curve (the enumerated encodings of a codestream that are not one of the
+// host's eight named profiles): conversion matrices through D50 (Bradford), and a matrix / TRC v4 profile describing the space - the
+// counterpart of the profile the reference's decoder library synthesises for JXL_COLOR_PROFILE_TARGET_DATA (Decoder/JxlDecoder.cpp:652-682).
+struct IccCurveSpec {
+  int kind = 0;        // 0 linear, 1 sRGB, 2 BT.709, 4 pure gamma: encoded = linear ^ gamma
+  double gamma = 1.0;
+};
+// RGB with these primaries and white point -> XYZ adapted to D50 (row-major)
+void PrimariesToXyzD50(const double prim_xy[3][2], const double white_xy[2], double out[9]);
+// linear sRGB (D65) -> linear RGB of the space
+bool MatrixFromLinearSrgb(const double prim_xy[3][2], const double white_xy[2], double out[9]);
+std::vector<uint8_t> IccSynthesize(bool gray, const double prim_xy[3][2], const double white_xy[2], const IccCurveSpec& curve, uint32_t rendering_intent);
+
 // What the decode path needs to know about a profile without a colour management system:
 //   colour space of the data (header bytes 16..19): 'RGB ', 'GRAY', 'CMYK', ...
 uint32_t IccDataColorSpace(const uint8_t* icc, size_t size);

@@ -82,7 +82,7 @@ class OracleError(RuntimeError):
 
 def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, seed=1, epf_iters=-1, gaborish=True,
            container=True, adaptive_lf_smoothing=True, lossless_predictor=6, lossless_squeeze=False, num_threads=8, exif=None,
-           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0, icc=None, cmyk=False):
+           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0, icc=None, cmyk=False, animation_frames=1):
     """px: uint8 array (h, w, nch) with nch in 1..4 (Gray, GrayA, RGB, RGBA); with bits > 8 (up to 16) a uint16 array whose
     samples use the low `bits` bits; with float_samples = 16 / 32 a float16 / float32 array (nominal range [0, 1]).  Returns bytes."""
     L = lib()
@@ -95,6 +95,9 @@ def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, 
     h, w, nch = px.shape
     p = EncodeParams(distance, int(lossless), 7, strategy_mode, fixed_strategy, seed, epf_iters, int(gaborish), int(container),
                      int(adaptive_lf_smoothing), lossless_predictor, int(lossless_squeeze), lossless_tree, num_threads, bits, orientation, float_samples, colour)
+    if animation_frames > 1:
+        L.jxo_set_next_animation.argtypes = [C.c_int]
+        L.jxo_set_next_animation(animation_frames)
     if icc or cmyk:
         L.jxo_set_next_icc.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
         L.jxo_set_next_icc(icc, len(icc) if icc else 0, int(cmyk))

@@ -64,3 +64,17 @@ def test_load_image_with_brotli_compressed_metadata(oracle):
     assert b.trace == ["setBasicInfo", "setKnownColorProfile", "setExif", "setXmp", "setLayerData"]
     assert b.exif == exif and b.xmp == xmp
     assert np.array_equal(a.pixels, b.pixels)
+
+
+@pytest.mark.parametrize("lossless", [False, True])
+def test_first_frame_of_an_animation_wins(oracle, lossless):
+    """Multi-frame files: the reference stops after the first full image (Decoder/JxlDecoder.cpp:398-400; HasAnimation / HasMultipleFrames
+    exist in the status enum and are never returned).  Frames 2 and 3 of the test file hold a different picture."""
+    img = synth(300, 280, 62)
+    kw = dict(lossless=True) if lossless else dict(distance=1.0)
+    one = api.load_image(oracle.encode(img, **kw))
+    ani = api.load_image(oracle.encode(img, animation_frames=3, **kw))
+    assert ani.trace.count("setLayerData") == 1
+    assert ani.pixels.shape == one.pixels.shape and (ani.pixels == one.pixels).all()
+    if lossless:
+        assert (ani.pixels == img).all()

@@ -113,3 +113,45 @@ def test_cmyk(oracle, alpha):
     got = api.load_image(data)
     assert got.format == "Cmyk" and got.has_transparency == alpha and got.icc == icc
     assert got.pixels.shape == want.shape and (got.pixels == want).all()
+
+
+def _model(icc):
+    import ctypes as C
+    L = api.lib()
+    L.jxlhip_icc_model.restype = C.c_int32
+    L.jxlhip_icc_model.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    model = np.zeros(18, np.float64)
+    to_lin = np.zeros(3 * 256, np.float32)
+    kind = L.jxlhip_icc_model(icc, len(icc), model.ctypes.data, to_lin.ctypes.data, None)
+    return kind, model[:9].reshape(3, 3), to_lin[:256]
+
+
+ADOBE = ((0.64, 0.33), (0.21, 0.71), (0.15, 0.06))
+
+
+@pytest.mark.parametrize("colour,prim,white,gamma", [(7, ADOBE, icc_util.D65, 256 / 563.0), (8, icc_util.PRIMARIES["p3"], (0.314, 0.351), 1 / 2.6),
+                                                     (9, icc_util.PRIMARIES["srgb"], (0.3457, 0.3585), 1.0)])
+def test_encodings_outside_the_named_profiles_get_a_synthesised_profile(oracle, colour, prim, white, gamma):
+    """Custom primaries / white points, explicit gamma, DCI: SetProfileFromColorEncoding (Decoder/JxlDecoder.cpp:36-108) knows none of
+    them, so the reference hands the host an ICC profile of the target data (:652-682).  Here: decoded into that space (parity with the
+    oracle) and described by a synthesised matrix / TRC profile, which is checked by evaluating it again."""
+    img = synth(330, 270, 64)
+    data = oracle.encode(img, colour=colour)
+    ref = oracle.decode(data).pixels
+    got = api.load_image(data)
+    assert got.known_profile is None and got.icc is not None and got.trace.count("setIccProfile") == 1
+    d = np.abs(got.pixels.astype(int) - ref.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (int(d.max()), float((d > 0).mean()))
+    kind, from_srgb, to_lin = _model(got.icc)
+    assert kind == 1
+    # the profile's colorants and curve against float64: Bradford-adapted primaries, power law
+    def to_d50(p, w):
+        m = icc_util.rgb_to_xyz(p, w)
+        cone = np.array([[0.8951, 0.2664, -0.1614], [-0.7502, 1.7135, 0.0367], [0.0389, -0.0685, 1.0296]])
+        wxyz = np.array([w[0] / w[1], 1.0, (1 - w[0] - w[1]) / w[1]])
+        gain = (cone @ np.array([0.96422, 1.0, 0.82521])) / (cone @ wxyz)
+        return np.linalg.inv(cone) @ np.diag(gain) @ cone @ m
+    want = np.linalg.inv(to_d50(prim, white)) @ to_d50(icc_util.PRIMARIES["srgb"], icc_util.D65)
+    assert np.abs(from_srgb - want).max() < 3e-4
+    x = np.arange(256) / 255
+    assert np.abs(to_lin - x ** (1 / gamma)).max() < 3e-4

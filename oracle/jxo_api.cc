@@ -2,6 +2,7 @@
 // Plain C entry points for ctypes (tests/, bench.py cpu_baseline leg, smoke()).
 #include "jxo_codec.h"
 #include "jxo_icc.h"
+#include "jxo_entropy.h"
 #include <string>
 
 using namespace jxo;
@@ -91,6 +92,8 @@ struct JxoEncodeParams {
 static thread_local std::vector<uint8_t> g_next_icc;
 static thread_local bool g_next_cmyk = false;
 static thread_local int g_next_frames = 1;
+static thread_local uint32_t g_next_flags = 0;   // 1: explicit (custom) dequantisation tables; 2: prefix codes; 4: LZ77
+void jxo_set_next_flags(uint32_t flags) { g_next_flags = flags; }
 void jxo_set_next_animation(int frames) { g_next_frames = frames; }
 void jxo_set_next_icc(const uint8_t* icc, size_t size, int cmyk) {
   g_next_icc.assign(icc ? icc : nullptr, icc ? icc + size : nullptr);
@@ -132,8 +135,15 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.icc.swap(g_next_icc); g_next_icc.clear();
     p.cmyk = g_next_cmyk; g_next_cmyk = false;
     p.animation_frames = g_next_frames; g_next_frames = 1;
+    p.custom_quant_tables = (g_next_flags & 1) != 0;
+    const uint32_t g_next_flags_entropy = g_next_flags;
+    g_next_flags = 0;
     JxoBytes* b = new JxoBytes();
-    b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
+    SetEntropyTestMode(((g_next_flags_entropy >> 1) & 3));
+    try {
+      b->b = EncodeJxl(px, w, h, nch, p, exif, exif_size, xmp, xmp_size);
+    } catch (...) { SetEntropyTestMode(0); delete b; throw; }
+    SetEntropyTestMode(0);
     return b;
   } catch (const std::exception& e) {
     g_err = e.what();

@@ -73,6 +73,7 @@ struct EncodeParams {
   int colour = 0;
   int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
   std::vector<uint8_t> icc;     // embedded ICC profile instead of the enumerated colour encoding
+  bool custom_quant_tables = false;   // lossy: every dequantisation table written explicitly (parameters scaled per table by `seed`)
   int animation_frames = 1;     // > 1: an animation; frame k > 0 shows the picture rotated by 180 degrees / inverted (any decoder
                                 // that returns something other than the first frame is caught)
   bool cmyk = false;            // lossless only: nch 4 / 5 = C, M, Y, K [, A] as STORED (0 = full ink); K goes to a black extra channel

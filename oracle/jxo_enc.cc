@@ -311,7 +311,9 @@ struct VarDctEncoder {
     global_scale = (uint32_t)std::max<long>(1, std::min<long>(8193 + 65535, std::lrint(65536.0 * qf / 16.0)));
     double lfq_f = 1.1 / std::max(0.05f, p.distance);
     quant_lf = (uint32_t)std::max<long>(1, std::min<long>(65536, std::lrint(lfq_f * 65536.0 / global_scale)));
-    dq.SetDefault();
+    BitWriter dq_bits;   // explicit tables: their HfGlobal bits are produced now, the quantiser uses the tables they describe
+    if (p.custom_quant_tables) dq.SetCustomAndWrite(p.seed, dq_bits);
+    else dq.SetDefault();
     bctx.SetDefault();
     ChooseStrategies();
     const float inv_gs = 65536.0f / global_scale;
@@ -480,6 +482,18 @@ struct VarDctEncoder {
     for (auto& t : lf_tok) sets.push_back(&t);
     for (auto& t : meta_tok) sets.push_back(&t);
     for (auto& t : alpha_tok) sets.push_back(&t);
+    // LZ77 distance multipliers: the widest channel of each Modular stream (LF: the three LF planes; HF metadata: chroma-from-luma
+    // maps, the two block-info rows, sharpness; alpha: the group)
+    for (uint32_t g = 0; g < nlf; g++) {
+      const int gx = g % f.xsize_lf_groups;
+      const int bwg = std::min((int)f.group_dim, w8 - gx * (int)f.group_dim);
+      SetStreamDistMult(&lf_tok[g], (uint32_t)bwg);
+      SetStreamDistMult(&meta_tok[g], std::max<uint32_t>((uint32_t)bwg, nb_blocks[g]));
+    }
+    for (size_t g = 0; g < alpha_tok.size(); g++) {
+      const int gx = alpha_global ? 0 : (int)(g % f.xsize_groups);
+      SetStreamDistMult(&alpha_tok[g], alpha_global ? (uint32_t)w : (uint32_t)std::min((int)f.group_dim, w - gx * (int)f.group_dim));
+    }
     EncOptions mo;
     mo.max_clusters = 32;
     EncCode mcode;
@@ -505,7 +519,8 @@ struct VarDctEncoder {
     }
     // --- HfGlobal
     BitWriter& hg = sec[1 + nlf];
-    hg.Bool(true);                          // default dequant matrices
+    if (p.custom_quant_tables) hg.Append(dq_bits);
+    else hg.Bool(true);                     // default dequant matrices
     hg.Write(CeilLog2(ng), 0);              // num_hf_presets - 1
     hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);  // used_orders: none
     std::vector<const std::vector<Token>*> acsets;
@@ -564,6 +579,11 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
   for (; first_group_channel < full.ch.size(); first_group_channel++)
     if (full.ch[first_group_channel].w > gd || full.ch[first_group_channel].h > gd) break;
   std::vector<Token> global_tok;
+  {
+    uint32_t dm = 0;
+    for (size_t c = 0; c < first_group_channel; c++) dm = std::max<uint32_t>(dm, (uint32_t)full.ch[c].w);
+    SetStreamDistMult(&global_tok, dm);
+  }
   for (size_t c = 0; c < first_group_channel; c++) TokenizeChannel(tree, wph, full, (int)c, 0, global_tok);
   auto group_tokens = [&](int x0, int y0, int xs, int ys, int min_shift, int max_shift, uint32_t sid, std::vector<Token>& out) -> bool {
     ModularImage sub;
@@ -581,6 +601,9 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
       sub.ch.push_back(ch);
     }
     if (sub.ch.empty()) return false;
+    uint32_t dm = 0;
+    for (auto& c : sub.ch) dm = std::max<uint32_t>(dm, (uint32_t)c.w);
+    SetStreamDistMult(&out, dm);   // LZ77 distance multiplier of the stream: its widest channel
     for (size_t c = 0; c < sub.ch.size(); c++) TokenizeChannel(tree, wph, sub, (int)c, sid, out);
     return true;
   };

@@ -1,5 +1,7 @@
 // ORACLE — test infrastructure only (see jxo_common.h header).
 #include "jxo_entropy.h"
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace jxo {
@@ -548,25 +550,174 @@ static double MergeCost(const RawHist& a, const RawHist& b) {
   return e - a.entropy - b.entropy;
 }
 
+// ---- test modes: prefix codes and LZ77
+static uint32_t g_entropy_test_mode = 0;
+void SetEntropyTestMode(uint32_t mode) { g_entropy_test_mode = mode; }
+static std::mutex g_dm_mutex;
+static std::map<const void*, uint32_t> g_dist_mult;
+void SetStreamDistMult(const std::vector<Token>* tokens, uint32_t dist_mult) {
+  std::lock_guard<std::mutex> lock(g_dm_mutex);
+  if (dist_mult) g_dist_mult[tokens] = dist_mult; else g_dist_mult.erase(tokens);
+}
+static uint32_t StreamDistMult(const void* tokens) {
+  std::lock_guard<std::mutex> lock(g_dm_mutex);
+  auto it = g_dist_mult.find(tokens);
+  return it == g_dist_mult.end() ? 0u : it->second;
+}
+
+namespace {
+const uint32_t kLzMinSymbol = 224, kLzMinLength = 3, kLzMaxLength = 200;
+struct Sym { uint32_t ctx, tok, nb, bits; };
+
+// Token stream -> emitted symbols.  With LZ77: a run of values equal to the value before it, or a stretch equal to the stretch
+// `dist_mult` symbols back, of at least kLzMinLength symbols becomes (length symbol in the position's context, distance symbol in
+// the extra context).  The window holds decoded VALUES, so matches are on Token::value; contexts of copied positions are never coded.
+void Symbolize(const std::vector<Token>& t, const HybridUintConfig& cfg, bool lz77, uint32_t dist_ctx, uint32_t dist_mult, std::vector<Sym>& out) {
+  out.clear();
+  const size_t n = t.size();
+  for (size_t i = 0; i < n;) {
+    size_t len = 0;
+    uint32_t dist_value = 0;
+    if (lz77 && i >= 1) {
+      size_t l1 = 0;
+      while (i + l1 < n && l1 < kLzMaxLength && t[i + l1].value == t[i - 1].value) l1++;
+      size_t l2 = 0;
+      if (dist_mult > 1 && i >= dist_mult)
+        while (i + l2 < n && l2 < kLzMaxLength && t[i + l2].value == t[i + l2 - dist_mult].value) l2++;
+      if (l2 > l1 && l2 >= kLzMinLength) { len = l2; dist_value = 0; }                        // special distance 0: (dx 0, dy 1) = dist_mult back
+      else if (l1 >= kLzMinLength) { len = l1; dist_value = dist_mult ? 1 : 0; }             // one back: special distance 1 (dx 1, dy 0), or 0 + 1
+    }
+    Sym s;
+    if (len) {
+      HybridUintConfig(4, 2, 0).Encode((uint32_t)(len - kLzMinLength), &s.tok, &s.nb, &s.bits);
+      s.tok += kLzMinSymbol;
+      s.ctx = t[i].ctx;
+      out.push_back(s);
+      cfg.Encode(dist_value, &s.tok, &s.nb, &s.bits);
+      s.ctx = dist_ctx;
+      out.push_back(s);
+      i += len;
+    } else {
+      cfg.Encode(t[i].value, &s.tok, &s.nb, &s.bits);
+      JXO_CHECK(!lz77 || s.tok < kLzMinSymbol, "literal token collides with the LZ77 symbols");
+      s.ctx = t[i].ctx;
+      out.push_back(s);
+      i++;
+    }
+  }
+}
+
+// Huffman code lengths (<= limit) for the counts; symbols with count 0 get length 0.  At least two symbols must be used.
+std::vector<uint8_t> HuffmanLengths(std::vector<uint64_t> counts, int limit) {
+  for (;;) {
+    struct Node { uint64_t w; int left, right; };
+    std::vector<Node> nodes;
+    std::vector<int> alive;
+    for (size_t i = 0; i < counts.size(); i++) { nodes.push_back({counts[i], -1, -1}); if (counts[i]) alive.push_back((int)i); }
+    JXO_CHECK(alive.size() >= 2, "Huffman needs two symbols");
+    while (alive.size() > 1) {
+      std::sort(alive.begin(), alive.end(), [&](int a, int b) { return nodes[a].w != nodes[b].w ? nodes[a].w > nodes[b].w : a > b; });
+      const int a = alive.back(); alive.pop_back();
+      const int b = alive.back(); alive.pop_back();
+      nodes.push_back({nodes[a].w + nodes[b].w, a, b});
+      alive.push_back((int)nodes.size() - 1);
+    }
+    std::vector<uint8_t> len(counts.size(), 0);
+    int maxlen = 0;
+    std::vector<std::pair<int, int>> stack = {{alive[0], 0}};
+    while (!stack.empty()) {
+      auto [nd, d] = stack.back();
+      stack.pop_back();
+      if (nodes[nd].left < 0) { len[nd] = (uint8_t)d; maxlen = std::max(maxlen, d); }
+      else { stack.push_back({nodes[nd].left, d + 1}); stack.push_back({nodes[nd].right, d + 1}); }
+    }
+    if (maxlen <= limit) return len;
+    for (auto& c : counts) if (c) c = std::max<uint64_t>(1, c >> 1);   // flatten and retry
+  }
+}
+// canonical codes (MSB first) from lengths
+std::vector<uint16_t> CanonicalCodes(const std::vector<uint8_t>& len) {
+  std::vector<uint16_t> code(len.size(), 0);
+  uint32_t next = 0;
+  for (int l = 1; l <= 15; l++) {
+    for (size_t i = 0; i < len.size(); i++) if (len[i] == l) code[i] = (uint16_t)next++;
+    next <<= 1;
+  }
+  return code;
+}
+void WriteMsbFirst(BitWriter& bw, uint32_t code, int len) { for (int b = len - 1; b >= 0; b--) bw.Write(1, (code >> b) & 1); }
+
+void WriteVarLenUint16(BitWriter& bw, uint32_t n) {
+  if (n == 0) { bw.Write(1, 0); return; }
+  bw.Write(1, 1);
+  const uint32_t nb = FloorLog2(n);
+  bw.Write(4, nb);
+  bw.Write(nb, n - (1u << nb));
+}
+
+// One prefix code in the complex form of RFC 7932 section 3.5 (no run-length symbols), or the one-symbol simple form.
+void WritePrefixCodeHeader(BitWriter& bw, const std::vector<uint8_t>& len, uint32_t alphabet_size) {
+  if (alphabet_size == 1) return;   // nothing is coded for a one-symbol alphabet
+  int used = 0, last = 0;
+  for (size_t i = 0; i < len.size(); i++) if (len[i]) { used++; last = (int)i; }
+  if (used == 1) {   // simple form, NSYM = 1
+    bw.Write(2, 1);
+    bw.Write(2, 0);
+    int nbits = 0;
+    for (uint32_t c = alphabet_size - 1; c; c >>= 1) nbits++;
+    bw.Write(nbits, last);
+    return;
+  }
+  // code-length code over the length values 0..15 that occur
+  std::vector<uint64_t> lc(18, 0);
+  for (int i = 0; i <= last; i++) lc[len[i]]++;
+  int lused = 0, lonly = 0;
+  for (int v = 0; v < 18; v++) if (lc[v]) { lused++; lonly = v; }
+  std::vector<uint8_t> cl(18, 0);
+  if (lused == 1) cl[lonly] = 1;   // (cannot happen with >= 2 used symbols of a complete code and zeros in between, but be safe)
+  else cl = HuffmanLengths(lc, 5);
+  static const uint8_t kOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  static const uint8_t kVlcBits[6] = {0x0, 0x7, 0x3, 0x2, 0x1, 0xF}, kVlcLen[6] = {2, 4, 3, 2, 2, 4};   // value -> LSB-first code
+  bw.Write(2, 0);   // HSKIP = 0
+  int space = 32, ncodes = 0;
+  for (int i = 0; i < 18 && space > 0; i++) {
+    const int v = cl[kOrder[i]];
+    bw.Write(kVlcLen[v], kVlcBits[v]);
+    if (v) { space -= 32 >> v; ncodes++; }
+  }
+  JXO_CHECK(space == 0 || ncodes == 1, "code-length code is not complete");
+  const std::vector<uint16_t> clcode = CanonicalCodes(cl);
+  for (int i = 0; i <= last; i++) WriteMsbFirst(bw, clcode[len[i]], ncodes == 1 ? 0 : cl[len[i]]);
+}
+}  // namespace
+
 void BuildAndWriteCode(const std::vector<const std::vector<Token>*>& token_sets, size_t num_contexts,
                        const EncOptions& opt, BitWriter& bw, EncCode& out) {
   out = EncCode();
   EntropyCode& code = out.code;
-  // 1. per-context raw histograms of token symbols
+  const bool use_prefix = opt.use_prefix || (opt.top_level && (g_entropy_test_mode & 1));
+  const bool lz77 = opt.lz77 || (opt.top_level && (g_entropy_test_mode & 2));
+  out.num_contexts = num_contexts;
+  const size_t data_contexts = num_contexts;
+  if (lz77) num_contexts++;   // the distance context
+  // 1. per-context raw histograms of the emitted symbols
   std::vector<RawHist> hist(num_contexts);
   uint32_t max_token = 0;
-  for (auto* ts : token_sets)
-    for (const Token& t : *ts) {
-      JXO_CHECK(t.ctx < num_contexts, "token context out of range");
-      uint32_t tok, nb, bits;
-      opt.cfg.Encode(t.value, &tok, &nb, &bits);
-      RawHist& h = hist[t.ctx];
-      if (h.c.size() <= tok) h.c.resize(tok + 1, 0);
-      h.c[tok]++;
-      h.total++;
-      max_token = std::max(max_token, tok);
-    }
-  JXO_CHECK(max_token < 256, "token alphabet exceeds ANS limit");
+  auto count = [&](uint32_t ctx, uint32_t tok) {
+    RawHist& h = hist[ctx];
+    if (h.c.size() <= tok) h.c.resize(tok + 1, 0);
+    h.c[tok]++;
+    h.total++;
+    max_token = std::max(max_token, tok);
+  };
+  std::vector<Sym> syms;
+  for (auto* ts : token_sets) {
+    for (const Token& t : *ts) JXO_CHECK(t.ctx < data_contexts, "token context out of range");
+    Symbolize(*ts, opt.cfg, lz77, (uint32_t)data_contexts, StreamDistMult(ts), syms);
+    for (const Sym& sy : syms) count(sy.ctx, sy.tok);
+  }
+  if (lz77) { count((uint32_t)data_contexts, 0); count((uint32_t)data_contexts, 1); }
+  JXO_CHECK(use_prefix || max_token < 256, "token alphabet exceeds ANS limit");
   for (auto& h : hist) h.entropy = HistEntropyBits(h.c, h.total);
   // 2. clustering
   code.ctx_map.assign(num_contexts, 0);
@@ -619,14 +770,20 @@ void BuildAndWriteCode(const std::vector<const std::vector<Token>*>& token_sets,
     clusters = sums;
   }
   code.num_hist = (uint32_t)clusters.size();
-  code.lz77 = false;
-  code.use_prefix = false;
-  code.log_alpha = std::max(5, CeilLog2(max_token + 1));
-  JXO_CHECK(code.log_alpha <= 8, "log_alpha");
+  code.lz77 = lz77;
+  code.lz_min_symbol = kLzMinSymbol; code.lz_min_length = kLzMinLength; code.lz_len_cfg = HybridUintConfig(4, 2, 0);
+  code.use_prefix = use_prefix;
+  code.log_alpha = use_prefix ? 15 : std::max(5, CeilLog2(max_token + 1));
+  JXO_CHECK(use_prefix || code.log_alpha <= 8, "log_alpha");
   code.cfg.assign(code.num_hist, opt.cfg);
   JXO_CHECK(opt.cfg.split_exponent <= code.log_alpha, "uint config vs alphabet");
   // 3. header
-  bw.Write(1, 0);  // lz77 disabled
+  bw.Write(1, lz77 ? 1 : 0);
+  if (lz77) {
+    bw.U32(Val(224), Val(512), Val(4096), BitsOff(15, 8), kLzMinSymbol);
+    bw.U32(Val(3), Val(4), BitsOff(2, 5), BitsOff(8, 9), kLzMinLength);
+    WriteUintConfig(bw, code.lz_len_cfg, 8);
+  }
   if (num_contexts > 1) {
     if (code.num_hist == 1) {
       bw.Write(1, 1);
@@ -643,15 +800,40 @@ void BuildAndWriteCode(const std::vector<const std::vector<Token>*>& token_sets,
       for (auto m : code.ctx_map) mt.emplace_back(0, m);
       EncOptions mo;
       mo.cfg = HybridUintConfig(4, 2, 0);
+      mo.top_level = false;
       EncCode mc;
       std::vector<const std::vector<Token>*> sets = {&mt};
       BuildAndWriteCode(sets, 1, mo, bw, mc);
       WriteTokens(mt, mc, bw);
     }
   }
-  bw.Write(1, 0);  // ANS, not prefix
-  bw.Write(2, code.log_alpha - 5);
+  bw.Write(1, use_prefix ? 1 : 0);
+  if (!use_prefix) bw.Write(2, code.log_alpha - 5);
   for (auto& c : code.cfg) WriteUintConfig(bw, c, code.log_alpha);
+  if (use_prefix) {
+    // alphabet sizes, then the codes
+    std::vector<uint32_t> asz(code.num_hist);
+    for (uint32_t k = 0; k < code.num_hist; k++) {
+      asz[k] = std::max<uint32_t>(1, (uint32_t)clusters[k].c.size());
+      while (asz[k] > 1 && clusters[k].c[asz[k] - 1] == 0) asz[k]--;
+      WriteVarLenUint16(bw, asz[k] - 1);
+    }
+    code.prefix.resize(code.num_hist);
+    out.pcode.resize(code.num_hist);
+    for (uint32_t k = 0; k < code.num_hist; k++) {
+      std::vector<uint64_t> cnt(asz[k], 0);
+      int used = 0;
+      for (uint32_t i = 0; i < asz[k] && i < clusters[k].c.size(); i++) { cnt[i] = clusters[k].c[i]; used += cnt[i] != 0; }
+      std::vector<uint8_t> len(asz[k], 0);
+      if (used >= 2) len = HuffmanLengths(cnt, 15);
+      else for (uint32_t i = 0; i < asz[k]; i++) if (cnt[i]) len[i] = 1;   // a single symbol: zero bits, its "length" only marks it
+      WritePrefixCodeHeader(bw, len, asz[k]);
+      if (used < 2) std::fill(len.begin(), len.end(), 0);
+      code.prefix[k].lengths = len;
+      out.pcode[k] = CanonicalCodes(len);
+    }
+    return;
+  }
   code.counts.resize(code.num_hist);
   code.alias.resize(code.num_hist);
   out.reverse_map.resize(code.num_hist);
@@ -682,15 +864,26 @@ void BuildAndWriteCode(const std::vector<const std::vector<Token>*>& token_sets,
 
 void WriteTokens(const std::vector<Token>& tokens, const EncCode& ec, BitWriter& bw) {
   const EntropyCode& code = ec.code;
-  size_t n = tokens.size();
+  std::vector<Sym> syms;
+  Symbolize(tokens, code.cfg[0], code.lz77, (uint32_t)ec.num_contexts, StreamDistMult(&tokens), syms);
+  const size_t n = syms.size();
+  if (code.use_prefix) {
+    for (const Sym& sy : syms) {
+      const uint32_t h = code.ctx_map[sy.ctx];
+      const std::vector<uint8_t>& len = code.prefix[h].lengths;
+      JXO_CHECK(sy.tok < len.size(), "symbol outside the prefix alphabet");
+      WriteMsbFirst(bw, ec.pcode[h][sy.tok], len[sy.tok]);
+      bw.Write(sy.nb, sy.bits);
+    }
+    return;
+  }
   std::vector<uint16_t> flush_bits(n);
   std::vector<uint8_t> flushed(n, 0);
   uint32_t state = kAnsSignature << 16;
   for (size_t r = n; r-- > 0;) {
-    const Token& t = tokens[r];
+    const Sym& t = syms[r];
     uint32_t h = code.ctx_map[t.ctx];
-    uint32_t tok, nb, bits;
-    code.cfg[h].Encode(t.value, &tok, &nb, &bits);
+    const uint32_t tok = t.tok;
     JXO_CHECK(tok < code.counts[h].size() && code.counts[h][tok] > 0, "token not in histogram");
     uint32_t freq = code.counts[h][tok];
     if ((state >> (32 - kAnsLogTabSize)) >= freq) {
@@ -702,12 +895,8 @@ void WriteTokens(const std::vector<Token>& tokens, const EncCode& ec, BitWriter&
   }
   bw.Write(32, state);
   for (size_t i = 0; i < n; i++) {
-    const Token& t = tokens[i];
-    uint32_t h = code.ctx_map[t.ctx];
-    uint32_t tok, nb, bits;
-    code.cfg[h].Encode(t.value, &tok, &nb, &bits);
     if (flushed[i]) bw.Write(16, flush_bits[i]);
-    bw.Write(nb, bits);
+    bw.Write(syms[i].nb, syms[i].bits);
   }
 }
 

@@ -105,18 +105,31 @@ struct EncCode {
   EntropyCode code;                                   // what the decoder will see
   std::vector<std::vector<uint16_t>> reverse_map;     // per histogram: [sym_start + offset] -> slot
   std::vector<std::vector<uint32_t>> sym_start;       // per histogram: start index of symbol in reverse_map
+  std::vector<std::vector<uint16_t>> pcode;           // prefix codes: per histogram, canonical code of each symbol (MSB first)
+  size_t num_contexts = 0;                            // without the LZ77 distance context
 };
 
 struct EncOptions {
   HybridUintConfig cfg = HybridUintConfig(4, 2, 0);
   int max_clusters = 64;   // <= 255
   bool force_single_cluster = false;
+  // Test streams (the reference's encoder library chooses these by effort; the oracle writes them on request so that decoders have
+  // something to read): prefix codes instead of ANS; LZ77 with runs (distance 1) and copies from `dist_mult` symbols back.
+  bool use_prefix = false;
+  bool lz77 = false;
+  bool top_level = true;   // false for the nested codes of context maps: never switched by SetEntropyTestMode
 };
+// Process-wide switch for the top-level codes the encoder writes from now on (bit 0: prefix codes, bit 1: LZ77).
+void SetEntropyTestMode(uint32_t mode);
 
 // Build a code (clustered ANS histograms) for `num_contexts` from all tokens of a stream
 // family, write its header; then write token sections with WriteTokens.
 void BuildAndWriteCode(const std::vector<const std::vector<Token>*>& token_sets, size_t num_contexts,
                        const EncOptions& opt, BitWriter& bw, EncCode& out);
 void WriteTokens(const std::vector<Token>& tokens, const EncCode& ec, BitWriter& bw);
+// The LZ77 distance multiplier the decoder will use for a token stream (0, the default: one-dimensional streams such as the HF
+// coefficients; Modular streams: the largest channel width of the sub-image).  Registered per token vector (by address) before the
+// code is built, because the choice of copies - hence the histograms - depends on it.
+void SetStreamDistMult(const std::vector<Token>* tokens, uint32_t dist_mult);
 
 }  // namespace jxo

@@ -633,6 +633,37 @@ void DequantMatrices::SetDefault() {
   for (int q = 0; q < kNumQuantTables; q++) ComputeQuantTable(q, LibraryEncoding(q), table[q], &n[q]);
 }
 
+void DequantMatrices::SetCustomAndWrite(uint32_t seed, BitWriter& bw) {
+  bw.Bool(false);   // not all_default
+  auto w16 = [&](float& v, float scale, float store_div) {   // parameter -> scaled, rounded to what F16 carries, written
+    v = RoundToF16(v * scale / store_div) * store_div;
+    bw.F16(v / store_div);
+  };
+  auto bands = [&](DctParams& pr, float scale) {
+    bw.Write(4, pr.num_bands - 1);
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < pr.num_bands; i++) w16(pr.bands[c][i], i == 0 ? scale : 1.0f, i == 0 ? 64.0f : 1.0f);
+  };
+  for (int q = 0; q < kNumQuantTables; q++) {
+    QuantEncoding e = LibraryEncoding(q);
+    const float scale = 1.0f + 0.04f * (float)((int)((seed * 7 + q * 13) % 7) - 3);   // 0.88 .. 1.12
+    bw.Write(3, e.mode);
+    switch (e.mode) {
+      case 1: for (int c = 0; c < 3; c++) for (int i = 0; i < 3; i++) w16(e.idweights[c][i], scale, 64.0f); break;
+      case 2: for (int c = 0; c < 3; c++) for (int i = 0; i < 6; i++) w16(e.dct2weights[c][i], scale, 64.0f); break;
+      case 3: for (int c = 0; c < 3; c++) for (int i = 0; i < 2; i++) w16(e.dct4multipliers[c][i], 1.0f, 1.0f); bands(e.dct, scale); break;
+      case 4: for (int c = 0; c < 3; c++) w16(e.dct4x8multipliers[c], 1.0f, 1.0f); bands(e.dct, scale); break;
+      case 5:
+        for (int c = 0; c < 3; c++) for (int i = 0; i < 9; i++) w16(e.afv_weights[c][i], i < 6 ? scale : 1.0f, i < 6 ? 64.0f : 1.0f);
+        bands(e.dct, scale); bands(e.dct_afv4x4, scale);
+        break;
+      case 6: bands(e.dct, scale); break;
+      default: throw Error("library encoding mode");
+    }
+    ComputeQuantTable(q, e, table[q], &n[q]);
+  }
+}
+
 void DequantMatrices::Decode(BitReader& br) {
   bool all_default = br.Bool();
   if (all_default) { SetDefault(); return; }

@@ -40,6 +40,9 @@ struct DequantMatrices {
   size_t n[kNumQuantTables];
   void SetDefault();
   void Decode(BitReader& br);  // HfGlobal: all_default bit + explicit encodings
+  // Encoder, test streams: every table written explicitly in its own encoding mode with the library's parameters scaled a little
+  // (per table, by `seed`); the tables are then computed from the F16-rounded parameters, i.e. exactly what a decoder will see.
+  void SetCustomAndWrite(uint32_t seed, BitWriter& bw);
   const float* Get(int strategy, int c) const {
     int q = kStrategyQuantTable[strategy];
     return table[q].data() + c * n[q];

@@ -76,9 +76,10 @@ static int OrderBucketOfQuantTable(int q) {
 }
 // Scan list of quant table q: for each channel (X, Y, B) and scan position k, the stored-layout index order[k] and the bits of
 // the dequantisation weight at that index.  custom: the frame's own coefficient orders ([bucket][channel], empty = natural).
-static void BuildScanList(int q, const std::vector<uint16_t> (*custom)[3], std::vector<U32x2>& out) {
+static void BuildScanList(int q, const std::vector<uint16_t> (*custom)[3], std::vector<U32x2>& out, const std::vector<float>* custom_dq = nullptr) {
   const StaticTables& st = GetStaticTables();
   const int o = OrderBucketOfQuantTable(q);
+  const std::vector<float>& dq = (custom_dq && custom_dq->size() == st.dq[q].size()) ? *custom_dq : st.dq[q];
   const size_t n = st.dq[q].size() / 3;
   out.resize(3 * n);
   for (int c = 0; c < 3; c++) {
@@ -86,7 +87,7 @@ static void BuildScanList(int q, const std::vector<uint16_t> (*custom)[3], std::
     for (size_t k = 0; k < n; k++) {
       const uint32_t p = k < ord.size() ? ord[k] : 0u;
       uint32_t wb;
-      const float w = st.dq[q][(size_t)c * n + (p < n ? p : 0)];
+      const float w = dq[(size_t)c * n + (p < n ? p : 0)];
       memcpy(&wb, &w, 4);
       out[(size_t)c * n + k] = U32x2{p, wb};
     }
@@ -380,8 +381,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)n);
   struct PerImg {
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
+    size_t m_pfx[3] = {}, a_pfx[3] = {};           // prefix codes: counts, symbol offsets, sorted symbols
+    size_t lz_lf = 0, lz_grp = 0, lz_hf = 0, lz_mod = 0;   // LZ77 windows (+1; 0: none)
     size_t scan[kNumQuantTables] = {};   // frames with their own coefficient orders: scan lists of the affected quant tables
     size_t trc_lut = 0;                  // tone-curve tables of an evaluated ICC profile (+1; 0: none)
+    size_t dq[kNumQuantTables] = {};     // frames with their own dequantisation tables (+1; 0: the library table)
     size_t z_cellinfo, z_status, centries, cblk;
     std::vector<size_t> mod_planes;
     size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
@@ -411,6 +415,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.m_cmap = blob.Take(f.mcode.ctx_map.size());
     l.m_cfg = blob.Take(4 * f.mcode.cfg.size());
     l.m_alias = blob.Take(8 * f.mcode.alias.size());
+    auto pfx_layout = [&](const HostCode& hc, size_t* o) {
+      if (!hc.use_prefix) return;
+      size_t total = 0;
+      for (auto& pc : hc.prefix) total += pc.sorted.size();
+      o[0] = blob.Take(2 * 16 * hc.prefix.size()); o[1] = blob.Take(4 * hc.prefix.size()); o[2] = blob.Take(2 * std::max<size_t>(1, total));
+    };
+    pfx_layout(f.mcode, l.m_pfx);
     if (f.encoding == 1) {
       // Modular (lossless) frame: whole-image int32 channel planes, no VarDCT workspace
       const bool resident_m = dev_data && dev_data[i] && f.cs_contiguous;
@@ -421,17 +432,23 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       l.mod_chan = blob.Take(sizeof(ModChanDev) * f.mod_coded.size());
       l.mod_desc = ws.Take(nsec * f.mod_coded.size() * sizeof(ChanDesc));
       if (f.tree_uses_wp) l.wp_grp = ws.Take(nsec * 10 * (f.group_dim + 2) * 4);
+      if (f.mcode.lz77) l.lz_mod = ws.Take(nsec * ((size_t)4 << 20)) + 1;
       n_mod_tasks += f.single ? 1 : ((int)nsec + mod_lanes - 1) / mod_lanes;
       continue;
     }
     l.a_cmap = blob.Take(f.acode.ctx_map.size());
     l.a_cfg = blob.Take(4 * f.acode.cfg.size());
     l.a_alias = blob.Take(8 * f.acode.alias.size());
+    pfx_layout(f.acode, l.a_pfx);
+    if (f.mcode.lz77) { l.lz_lf = ws.Take((size_t)f.nlf * ((size_t)4 << 20)) + 1; l.lz_grp = ws.Take((size_t)f.ng * ((size_t)4 << 16)) + 1; }
+    if (f.acode.lz77) l.lz_hf = ws.Take((size_t)f.ng * ((size_t)4 << 18)) + 1;
     for (int o = 0; o < kNumOrders; o++)
       for (int c = 0; c < 3; c++) l.order[o][c] = f.custom_order[o][c].empty() ? 0 : blob.Take(2 * f.custom_order[o][c].size());
     for (int q = 0; q < kNumQuantTables; q++) {
       const int o = OrderBucketOfQuantTable(q);
-      if (!f.custom_order[o][0].empty() || !f.custom_order[o][1].empty() || !f.custom_order[o][2].empty()) l.scan[q] = blob.Take(8 * 3 * (size_t)dq_n[q], 256) + 1;
+      const bool own_dq = !f.dq_default && f.custom_dq[q].size() == 3 * (size_t)dq_n[q];
+      if (own_dq) l.dq[q] = blob.Take(4 * 3 * (size_t)dq_n[q], 256) + 1;
+      if (own_dq || !f.custom_order[o][0].empty() || !f.custom_order[o][1].empty() || !f.custom_order[o][2].empty()) l.scan[q] = blob.Take(8 * 3 * (size_t)dq_n[q], 256) + 1;
     }
     const bool resident = dev_data && dev_data[i] && f.cs_contiguous;
     l.cs = resident ? 0 : blob.Take(f.cs_size + 16);
@@ -627,15 +644,36 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     put(l.sec_off, f.sec_off.data(), 8 * f.sec_off.size());
     put(l.sec_size, f.sec_size.data(), 4 * f.sec_size.size());
     put(l.tree, f.tree.data(), sizeof(DevTreeNode) * f.tree.size());
-    auto code = [&](const HostCode& hc, size_t cm, size_t cf, size_t al, DevCode& dc) {
+    auto code = [&](const HostCode& hc, size_t cm, size_t cf, size_t al, DevCode& dc, const size_t* pfx = nullptr) {
       put(cm, hc.ctx_map.data(), hc.ctx_map.size());
       std::vector<uint32_t> cfgp(hc.cfg.size());
       for (size_t k = 0; k < hc.cfg.size(); k++) {
         cfgp[k] = hc.cfg[k].split | hc.cfg[k].msb << 4 | hc.cfg[k].lsb << 8;
+        if (hc.use_prefix) {   // one-symbol prefix codes read no bits
+          if (hc.prefix[k].single >= 0) cfgp[k] |= 1u << 12 | (uint32_t)hc.prefix[k].single << 16;
+          continue;
+        }
         // single-symbol clusters: decoding never changes the ANS state nor reads bits (alias special form)
         const uint64_t e0 = hc.alias[k << hc.log_alpha];
         const uint32_t x0 = (uint32_t)e0, y0 = (uint32_t)(e0 >> 32);
         if ((x0 >> 16) == 0 && (y0 >> 16) == 4096) cfgp[k] |= 1u << 12 | ((x0 >> 8) & 0xFF) << 16;
+      }
+      dc.slow = (hc.use_prefix ? 1u : 0u) | (hc.lz77 ? 2u : 0u);
+      if (hc.use_prefix && pfx) {
+        std::vector<uint16_t> counts(16 * hc.prefix.size(), 0), sorted;
+        std::vector<uint32_t> offs(hc.prefix.size(), 0);
+        for (size_t k = 0; k < hc.prefix.size(); k++) {
+          memcpy(&counts[16 * k], hc.prefix[k].count, 32);
+          offs[k] = (uint32_t)sorted.size();
+          sorted.insert(sorted.end(), hc.prefix[k].sorted.begin(), hc.prefix[k].sorted.end());
+        }
+        put(pfx[0], counts.data(), 2 * counts.size()); put(pfx[1], offs.data(), 4 * offs.size()); put(pfx[2], sorted.data(), 2 * sorted.size());
+        dc.pfx_count = (const uint16_t*)(d_blob + pfx[0]); dc.pfx_off = (const uint32_t*)(d_blob + pfx[1]); dc.pfx_sorted = (const uint16_t*)(d_blob + pfx[2]);
+      }
+      if (hc.lz77) {
+        dc.lz_min_symbol = hc.lz_min_symbol; dc.lz_min_length = hc.lz_min_length;
+        dc.lz_len_cfg = hc.lz_len.split | hc.lz_len.msb << 4 | hc.lz_len.lsb << 8;
+        dc.lz_dist_cluster = hc.ctx_map.back();
       }
       put(cf, cfgp.data(), 4 * cfgp.size());
       put(al, hc.alias.data(), 8 * hc.alias.size());
@@ -646,7 +684,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       dc.num_clusters = hc.num_hist;
       dc.log_alpha = hc.log_alpha;
     };
-    code(f.mcode, l.m_cmap, l.m_cfg, l.m_alias, d.mcode);
+    code(f.mcode, l.m_cmap, l.m_cfg, l.m_alias, d.mcode, l.m_pfx);
     d.sec_off = (const uint64_t*)(d_blob + l.sec_off);
     d.sec_size = (const uint32_t*)(d_blob + l.sec_size);
     d.tree = (const DevTreeNode*)(d_blob + l.tree);
@@ -685,6 +723,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.mod_first_group = (int32_t)f.mod_first_group_channel;
       d.mod_desc = (ChanDesc*)(wr + l.mod_desc);
       if (f.tree_uses_wp) { d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * ((int64_t)f.group_dim + 2); }
+      if (l.lz_mod) d.lz_mod = (uint32_t*)(wr + l.lz_mod - 1);
       if (!inline_rct)
         for (auto& op : f.mod_ops) {
           const ParsedFrame::ModPlane &pa = f.mod_planes[op.a], &pb = f.mod_planes[op.b];
@@ -705,7 +744,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       else for (uint32_t g = 0; g < nsec; g += mod_lanes) mod_tasks[nmod_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(mod_lanes, nsec - g), 0};
       continue;
     }
-    code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode);
+    code(f.acode, l.a_cmap, l.a_cfg, l.a_alias, d.acode, l.a_pfx);
+    if (l.lz_lf) d.lz_lf = (uint32_t*)(wr + l.lz_lf - 1);
+    if (l.lz_grp) d.lz_grp = (uint32_t*)(wr + l.lz_grp - 1);
+    if (l.lz_hf) d.lz_hf = (uint32_t*)(wr + l.lz_hf - 1);
     d.num_presets = f.num_presets;
     d.num_block_ctx = f.num_block_ctx;
     memcpy(d.block_ctx_map, f.block_ctx_map.data(), std::min(sizeof(d.block_ctx_map), f.block_ctx_map.size()));
@@ -729,9 +771,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     memcpy(d.qbias, f.qbias, sizeof(d.qbias));
     for (int q = 0; q < kNumQuantTables; q++) {
       d.dq[q] = d_dq[q]; d.dq_n[q] = dq_n[q]; d.scan[q] = d_scan[q];
+      if (l.dq[q]) { put(l.dq[q] - 1, f.custom_dq[q].data(), 4 * f.custom_dq[q].size()); d.dq[q] = (const float*)(d_blob + l.dq[q] - 1); }
       if (l.scan[q]) {
         std::vector<U32x2> sl;
-        BuildScanList(q, f.custom_order, sl);
+        BuildScanList(q, f.custom_order, sl, l.dq[q] ? &f.custom_dq[q] : nullptr);
         put(l.scan[q] - 1, sl.data(), sl.size() * sizeof(U32x2));
         d.scan[q] = (const U32x2*)(d_blob + l.scan[q] - 1);
       }
@@ -930,6 +973,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
 // LF stage of ONE single-section frame on temporary buffers, synchronously: yields the bit position where HfGlobal starts,
 // which the host then parses (ParseHfGlobalAt).  The main pass decodes the (tiny) LF group again with everything in place.
 void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
+  if (f.mcode.use_prefix || f.mcode.lz77)
+    throw ParseError(DecoderStatus_DecodeError, "prefix-coded / LZ77 Modular streams in a frame that fits one group are not supported yet");
   Bump b;
   const size_t cells = (size_t)f.w8 * f.h8;
   const size_t o_img = b.Take(sizeof(DevImage)), o_task = b.Take(sizeof(SectionTask));

@@ -44,7 +44,13 @@ struct DevCode {
   uint32_t num_ctx;
   uint32_t num_clusters;
   uint32_t log_alpha;
-  uint32_t pad;
+  uint32_t slow;            // bit 0: prefix codes (log_alpha 15, no alias tables), bit 1: LZ77 - both take the general symbol reader
+  // prefix codes: per cluster 16 counts of codes per length (canonical code), the symbols sorted by (length, value)
+  const uint16_t* pfx_count;   // [cluster * 16 + length]
+  const uint16_t* pfx_sorted;  // [pfx_off[cluster] + rank]
+  const uint32_t* pfx_off;
+  // LZ77: symbols >= lz_min_symbol start a copy; its length uses lz_len_cfg (packed like cfg), its distance the cluster of the last context
+  uint32_t lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_cluster;
 };
 
 // Outcome of phase A (one lane per section) for one Modular channel; phase B (a wavefront per channel) finishes it.
@@ -156,6 +162,11 @@ struct DevImage {
   int32_t* wp_lf;           // [nlf][kWpLfInts]
   int32_t* wp_grp;          // [ng][wp_grp_ints]
   int64_t wp_grp_ints;
+  // LZ77 windows (allocated only for codes that use it): decoded values of one stream, 2^log entries per lane
+  uint32_t* lz_lf;          // per LF group, 2^20
+  uint32_t* lz_grp;         // per group (alpha stream), 2^16
+  uint32_t* lz_hf;          // per group (HF coefficient stream), 2^18
+  uint32_t* lz_mod;         // per section of a Modular frame, 2^20
   int32_t* alpha32;         // w*h decoded alpha (aliases tmp[0])
   // HF coefficients as decoded (hf_decode_kernel -> recon_tile_kernel): sparse entry lists per group, see kGroupEntriesCap.
   uint32_t* centries;       // group g at centries + (g - centries_g0) * kGroupEntriesCap

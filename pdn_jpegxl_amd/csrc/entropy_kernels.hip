@@ -66,6 +66,12 @@ struct LaneBitsT {
   int skip;
   uint32_t pend[kBatch];       // words [filled, filled + kBatch) as requested by the previous top-up, not yet in the ring
   bool has_pend;
+  // state of the general symbol reader (prefix codes / LZ77), per stream like the bit position
+  JXL_GLB uint32_t* lz_win;    // window of decoded values (LZ77), lz_mask + 1 entries
+  uint32_t lz_mask, lz_dm, lz_copy, lz_src, lz_done, slow_err;
+  __device__ __forceinline__ void SetLz(uint32_t* win, uint32_t log_size, uint32_t dist_mult) {
+    lz_win = (JXL_GLB uint32_t*)win; lz_mask = (1u << log_size) - 1; lz_dm = dist_mult;
+  }
   __device__ __forceinline__ void Fetch(uint32_t* v) {   // words [filled, filled + kBatch) into registers
     static_assert(kBatch == 4 || kBatch == 8, "one or two 16-byte loads");
     if (filled + kBatch <= nwords) {
@@ -111,6 +117,7 @@ struct LaneBitsT {
     const uintptr_t end = ((uintptr_t)cs + cs_size + 3) & ~(uintptr_t)3;
     nwords = end > al ? (uint32_t)((end - al) >> 2) : 0u;
     rd = 0; filled = 0; buf = 0; n = 0; has_pend = false;
+    lz_win = nullptr; lz_mask = 0; lz_dm = 0; lz_copy = 0; lz_src = 0; lz_done = 0; slow_err = 0;
     skip = (int)(addr - al) * 8 + (int)(bit_off & 7);
     TopUpSync();
     rd = (uint32_t)skip >> 5;   // whole words before the start are skipped, the rest bit by bit
@@ -163,6 +170,8 @@ struct CodeTab {
   typename AS<kLds>::U32 cfg;     // split | msb << 4 | lsb << 8 | degenerate << 12 | symbol << 16
   typename AS<kLds>::U64 alias;
   uint32_t log_alpha;
+  uint32_t slow;        // DevCode::slow (uniform over the workgroup: one image's code)
+  const DevCode* dc;    // the prefix / LZ77 parameters stay in global memory
 };
 
 __device__ __forceinline__ DevTreeNode NodeOf(I4 v) {
@@ -200,8 +209,93 @@ __device__ __forceinline__ uint32_t AnsSym(LaneBits& b, uint32_t& state, typenam
   return sym;
 }
 
+// The general symbol reader: prefix codes (canonical code walked one length at a time over the next 15 bits) and LZ77 (a window of
+// decoded values per stream in global memory; copies, special two-dimensional distances).  Compatibility path: correct, not tuned -
+// streams written with these options are decoded several times slower than ANS streams without LZ77.
+__device__ const int8_t d_special_dist[120][2] = {
+    {0, 1}, {1, 0}, {1, 1}, {-1, 1}, {0, 2}, {2, 0}, {1, 2}, {-1, 2}, {2, 1}, {-2, 1}, {2, 2}, {-2, 2}, {0, 3}, {3, 0}, {1, 3},
+    {-1, 3}, {3, 1}, {-3, 1}, {2, 3}, {-2, 3}, {3, 2}, {-3, 2}, {0, 4}, {4, 0}, {1, 4}, {-1, 4}, {4, 1}, {-4, 1}, {3, 3}, {-3, 3},
+    {2, 4}, {-2, 4}, {4, 2}, {-4, 2}, {0, 5}, {3, 4}, {-3, 4}, {4, 3}, {-4, 3}, {5, 0}, {1, 5}, {-1, 5}, {5, 1}, {-5, 1}, {2, 5},
+    {-2, 5}, {5, 2}, {-5, 2}, {4, 4}, {-4, 4}, {3, 5}, {-3, 5}, {5, 3}, {-5, 3}, {0, 6}, {6, 0}, {1, 6}, {-1, 6}, {6, 1}, {-6, 1},
+    {2, 6}, {-2, 6}, {6, 2}, {-6, 2}, {4, 5}, {-4, 5}, {5, 4}, {-5, 4}, {3, 6}, {-3, 6}, {6, 3}, {-6, 3}, {0, 7}, {7, 0}, {1, 7},
+    {-1, 7}, {5, 5}, {-5, 5}, {7, 1}, {-7, 1}, {4, 6}, {-4, 6}, {6, 4}, {-6, 4}, {2, 7}, {-2, 7}, {7, 2}, {-7, 2}, {3, 7}, {-3, 7},
+    {7, 3}, {-7, 3}, {5, 6}, {-5, 6}, {6, 5}, {-6, 5}, {8, 0}, {4, 7}, {-4, 7}, {7, 4}, {-7, 4}, {8, 1}, {8, 2}, {6, 6}, {-6, 6},
+    {8, 3}, {5, 7}, {-5, 7}, {7, 5}, {-7, 5}, {8, 4}, {6, 7}, {-6, 7}, {7, 6}, {-7, 6}, {8, 5}, {7, 7}, {-7, 7}, {8, 6}, {8, 7}};
+
+template <bool kLds, class Bits>
+__device__ __noinline__ uint32_t SlowSymbol(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t cl) {
+  const DevCode& dc = *t.dc;
+  if (dc.slow & 1) {
+    const uint32_t c = t.cfg[cl];
+    if (c & 0x1000) return c >> 16;   // one-symbol code: no bits
+    b.Refill();
+    const uint32_t bits = (uint32_t)b.buf;
+    const uint16_t* cnt = dc.pfx_count + cl * 16;
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l < 16; l++) {
+      code |= (bits >> (l - 1)) & 1;
+      const int k = cnt[l];
+      if (code - k < first) {
+        b.buf >>= l; b.n -= l;
+        return dc.pfx_sorted[dc.pfx_off[cl] + index + code - first];
+      }
+      index += k; first = (first + k) << 1; code <<= 1;
+    }
+    b.slow_err = 1;
+    return 0;
+  }
+  const uint32_t le = 12 - t.log_alpha;
+  const uint32_t res = state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
+  const uint64_t e = t.alias[(cl << t.log_alpha) | i];
+  const uint32_t x = (uint32_t)e, y = (uint32_t)(e >> 32);
+  const bool g = pos >= (x & 0xFF);
+  const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
+  const uint32_t off = g ? (y & 0xFFFF) + pos : pos;
+  const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
+  state = freq * (state >> 12) + off;
+  if (state < 65536u) state = (state << 16) | b.Read(16);
+  return sym;
+}
+
+template <bool kLds, class Bits>
+__device__ __noinline__ uint32_t SlowGet(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
+  const DevCode& dc = *t.dc;
+  const bool lz = (dc.slow & 2) != 0 && b.lz_win != nullptr;
+  if (lz && b.lz_copy) {
+    const uint32_t v = b.lz_win[(b.lz_src++) & b.lz_mask];
+    b.lz_copy--;
+    b.lz_win[(b.lz_done++) & b.lz_mask] = v;
+    return v;
+  }
+  const uint32_t cl = t.cmap[ctx];
+  const uint32_t sym = SlowSymbol(b, state, t, cl);
+  if ((dc.slow & 2) && sym >= dc.lz_min_symbol) {
+    if (!lz) { b.slow_err = 1; return 0; }   // a copy in a stream that was given no window
+    const uint32_t len = HybridTail(b, dc.lz_len_cfg, sym - dc.lz_min_symbol) + dc.lz_min_length;
+    const uint32_t dcl = dc.lz_dist_cluster;
+    uint32_t dist = HybridTail(b, t.cfg[dcl], SlowSymbol(b, state, t, dcl));
+    if (b.lz_dm == 0) dist++;
+    else if (dist < 120) { const int o = d_special_dist[dist][0] + (int)b.lz_dm * d_special_dist[dist][1]; dist = o < 1 ? 1u : (uint32_t)o; }
+    else dist -= 119;
+    dist = min(dist, min(b.lz_done, 1u << 20));
+    if (dist == 0 || b.lz_done > b.lz_mask + 1) { b.slow_err = 1; return 0; }   // nothing to copy from / a stream longer than its window
+    b.lz_src = b.lz_done - dist;
+    b.lz_copy = len - 1;
+    const uint32_t v = b.lz_win[(b.lz_src++) & b.lz_mask];
+    b.lz_win[(b.lz_done++) & b.lz_mask] = v;
+    return v;
+  }
+  const uint32_t v = HybridTail(b, t.cfg[cl], sym);
+  if (lz) b.lz_win[(b.lz_done++) & b.lz_mask] = v;
+  return v;
+}
+// first value of a stream's ANS state: read from the stream, except for prefix codes (no state)
+template <bool kLds, class Bits>
+__device__ __forceinline__ uint32_t InitAnsState(Bits& b, const CodeTab<kLds>& t) { return (t.slow & 1) ? 0x130000u : b.Read(32); }
+
 template <bool kLds, class Bits>
 __device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
+  if (t.slow) return SlowGet(b, state, t, ctx);   // uniform over the wavefront: one image, one code
   const uint32_t cl = t.cmap[ctx];
   const uint32_t le = 12 - t.log_alpha;
   const uint32_t res = state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
@@ -219,7 +313,7 @@ __device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeT
 
 // Cooperative copy of a code's tables into LDS; returns the carved end offset.
 __device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, const DevCode& dc, CodeTab<true>& t, int tid, int nt) {
-  const uint32_t na = dc.num_clusters << dc.log_alpha;
+  const uint32_t na = (dc.slow & 1) ? 0u : dc.num_clusters << dc.log_alpha;   // prefix codes have no alias tables
   off = (off + 7) & ~(size_t)7;
   JXL_LDS uint64_t* sa = (JXL_LDS uint64_t*)(smem + off); off += (size_t)na * 8;
   JXL_LDS uint32_t* sc = (JXL_LDS uint32_t*)(smem + off); off += (size_t)dc.num_clusters * 4;
@@ -227,12 +321,12 @@ __device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, c
   for (uint32_t i = tid; i < na; i += nt) sa[i] = dc.alias[i];
   for (uint32_t i = tid; i < dc.num_clusters; i += nt) sc[i] = dc.cfg[i];
   for (uint32_t i = tid; i < dc.num_ctx; i += nt) sm[i] = dc.ctx_map[i];
-  t.cmap = sm; t.cfg = sc; t.alias = sa; t.log_alpha = dc.log_alpha;
+  t.cmap = sm; t.cfg = sc; t.alias = sa; t.log_alpha = dc.log_alpha; t.slow = dc.slow; t.dc = &dc;
   return off;
 }
 
 __device__ __forceinline__ void GlobalCode(const DevCode& dc, CodeTab<false>& t) {
-  t.cmap = dc.ctx_map; t.cfg = dc.cfg; t.alias = dc.alias; t.log_alpha = dc.log_alpha;
+  t.cmap = dc.ctx_map; t.cfg = dc.cfg; t.alias = dc.alias; t.log_alpha = dc.log_alpha; t.slow = dc.slow; t.dc = &dc;
 }
 
 // ------------------------------------------------------------------ Modular channel
@@ -393,7 +487,7 @@ __device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>
         rroot = v > nd.splitval ? nd.a : nd.b;
       }
       row_leaf = leaf.property < 0;
-      if (row_leaf && !use_wp) {
+      if (row_leaf && !use_wp && !tab.slow) {
         const uint32_t lp = leaf.a & 0xFF;
         if (lp == 0 || lp == 1 || lp == 2 || lp == 5) {
           if (lp == 0) LeafRow<kLds, 0>(b, state, tab, leaf, w, y, row, stride, rb, rs, use_rb);
@@ -554,7 +648,8 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
   bool needs_n = false;
   int32_t cval = 0;
   // a tree that references the weighted predictor anywhere keeps every channel on the generic path (its state is per sample)
-  const int cls = wp_scratch ? 0 : ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
+  // (prefix-coded / LZ77 streams too: their symbols come from the general reader, one AnsGet per sample)
+  const int cls = (wp_scratch || tab.slow) ? 0 : ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
   if (cls == 2) { d.kind = kChanConst; d.value = cval; *desc = d; return; }
   if (cls == 0) {
     RowBuf<kLds> rbuf;
@@ -831,9 +926,12 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
   uint32_t state = 0, err = 0, count = 1;
   int32_t* const wps = im.wp_lf ? im.wp_lf + (size_t)g * kWpLfInts : nullptr;
+  uint32_t* const lzw = im.lz_lf ? im.lz_lf + ((size_t)g << 20) : nullptr;   // LZ77 window of this lane's streams
   if (im.single && im.alpha_in_global) {
     // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
-    state = b.Read(32);
+    b.SetLz(lzw, 20, (uint32_t)im.w);
+    b.lz_copy = 0; b.lz_done = 0;
+    state = InitAnsState(b, mt.tab);
     DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc, wps);
     if (state != 0x130000u) err |= kErrBitstream;
   }
@@ -844,13 +942,20 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   // seven channels, one loop (a single inlined copy of the channel decoder): 0-2 LF coefficients, 3-6 HF metadata
 #pragma unroll 1
   for (int i = 0; i < 7 && !err; i++) {
-    if (i == 0) state = b.Read(32);
+    if (i == 0) {   // the LF stream: three channels bw wide
+      b.SetLz(lzw, 20, (uint32_t)bw);
+      b.lz_copy = 0; b.lz_done = 0;
+      state = InitAnsState(b, mt.tab);
+    }
     if (i == 3) {
       if (state != 0x130000u) { err |= kErrBitstream; break; }
       count = b.Read(CeilLog2D((uint32_t)(bw * bh))) + 1;
       if (count > (uint32_t)(bw * bh)) { err |= kErrBlockLayout; break; }
       if (b.Read(4) != 3) { err |= kErrUnsupportedHeader; break; }
-      state = b.Read(32);
+      // the HF metadata stream: chroma-from-luma maps (tw wide), block info (count wide), sharpness (bw wide)
+      b.SetLz(lzw, 20, max(max((uint32_t)tw, count), (uint32_t)bw));
+      b.lz_copy = 0; b.lz_done = 0;
+      state = InitAnsState(b, mt.tab);
     }
     int chan, sid, w, h, stride;
     int32_t* out;
@@ -866,7 +971,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
     }
     DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, desc + i, wps);
   }
-  if (!err && (state != 0x130000u || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
+  if (!err && (state != 0x130000u || b.slow_err || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
   if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
   im.lf_count[g] = err ? 0u : count;
   if (err) SetError(im, err, 1, g);
@@ -1100,7 +1205,8 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const uint32_t nbc = im.num_block_ctx;
   const uint32_t ctx_offset = preset * nbc * 495;
   uint32_t err = preset >= (uint32_t)im.num_presets ? (uint32_t)kErrBitstream : 0u;
-  uint32_t state = b.Read(32);
+  if (im.lz_hf) b.SetLz(im.lz_hf + ((size_t)g << 18), 18, 0);   // one-dimensional stream: plain distances
+  uint32_t state = InitAnsState(b, tab);
   const int gx = g % im.xg, gy = g / im.xg;
   // block descriptors: staged through a small LDS queue that is topped up together with the bit window
   const JXL_GLB uint32_t* const list = G(im.blk_list + (size_t)g * 1024);
@@ -1241,7 +1347,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       if (++k >= size && nzeros != 0) { err |= kErrBitstream; break; }
     }
   }
-  if (!err && state != 0x130000u) err |= kErrBitstream;
+  if (!err && (state != 0x130000u || b.slow_err)) err |= kErrBitstream;
   const uint64_t used = b.Consumed();
   if (!err && sec_bits + used > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   im.grp_bitpos[g] = err ? ~(uint64_t)0 : sec_bits + used;
@@ -1276,13 +1382,14 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
   uint32_t err = 0;
   if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
   else {
-    uint32_t state = b.Read(32);
     const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
     const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
+    if (im.lz_grp) b.SetLz(im.lz_grp + ((size_t)g << 16), 16, (uint32_t)gw);
+    uint32_t state = InitAnsState(b, mt.tab);
     const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
     DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc,
                             im.wp_grp ? im.wp_grp + (size_t)g * im.wp_grp_ints : nullptr);
-    if (state != 0x130000u) err |= kErrBitstream;
+    if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
     if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
   if (err) {
@@ -1411,7 +1518,13 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
       b.Init(im.cs, im.cs_size, im.mod_data_bits, (JXL_LDS uint32_t*)smem + lane, 64);
     }
     if (kind != 0 && b.Read(4) != 3) { err |= kErrUnsupportedHeader; break; }
-    uint32_t state = b.Read(32);
+    if (im.lz_mod) {   // LZ77: distance multiplier = the widest channel of this section
+      uint32_t dm = 0;
+      for (int c = 0; c < im.mod_ncoded; c++) { ModRect r; if (ModSectionRect(im, kind, g, im.mod_chan[c], c, &r)) dm = max(dm, (uint32_t)r.w); }
+      b.SetLz(im.lz_mod + ((size_t)s << 20), 20, dm);
+      b.lz_copy = 0; b.lz_done = 0;
+    }
+    uint32_t state = InitAnsState(b, mt.tab);
     int sub = 0;
 #pragma unroll 1
     for (int c = 0; c < im.mod_ncoded; c++) {
@@ -1422,7 +1535,7 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
                               (wps && wp_local && r.w <= rb_width) ? wp_local : wps, rb_width ? &rows : nullptr);
       sub++;
     }
-    if (state != 0x130000u) err |= kErrBitstream;
+    if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
     if (!im.single && start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   }
   if (err) {

@@ -1480,7 +1480,6 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
     f.mod_data_bits = f.after_lf_global_bits;
   }
   if (f.tree_uses_ref) Fail("MA trees using reference-channel properties (16 and up) are not supported on the GPU path yet");
-  if (f.mcode.use_prefix || f.mcode.lz77) Fail("prefix-coded / LZ77 modular streams are not supported on the GPU path yet");
   if (f.encoding == 1) {
     if (!f.has_global_tree) Fail("Modular frames without a global MA tree are not supported on the GPU path yet");
     return;   // nothing else is global in a Modular frame: every group section is decoded on the GPU
@@ -1490,11 +1489,8 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   if (f.single) return;
   {
     Bits s(f.cs + f.sec_off[1 + f.nlf], f.sec_size[1 + f.nlf]);
-    std::vector<float> custom[kNumQuantTables];
-    ReadHfGlobal(s, f, custom);
-    if (!f.dq_default) Fail("custom quantisation tables are not supported on the GPU path yet");
+    ReadHfGlobal(s, f, f.custom_dq);
   }
-  if (f.acode.use_prefix || f.acode.lz77) Fail("prefix-coded / LZ77 coefficient streams are not supported on the GPU path yet");
 }
 
 uint64_t ParseHfGlobalAt(ParsedFrame& f, uint64_t bit_pos) {
@@ -1502,10 +1498,7 @@ uint64_t ParseHfGlobalAt(ParsedFrame& f, uint64_t bit_pos) {
   if (bit_pos < sec_bits || bit_pos > sec_bits + (uint64_t)f.sec_size[0] * 8) Fail("LF group ends outside its section");
   Bits s(f.cs + f.sec_off[0], f.sec_size[0]);
   s.Skip(bit_pos - sec_bits);
-  std::vector<float> custom[kNumQuantTables];
-  ReadHfGlobal(s, f, custom);
-  if (!f.dq_default) Fail("custom quantisation tables are not supported on the GPU path yet");
-  if (f.acode.use_prefix || f.acode.lz77) Fail("prefix-coded / LZ77 coefficient streams are not supported on the GPU path yet");
+  ReadHfGlobal(s, f, f.custom_dq);
   for (int o = 0; o < kNumOrders; o++)
     for (int c = 0; c < 3; c++)
       if (!f.custom_order[o][c].empty()) Fail("custom coefficient orders in single-group frames are not supported on the GPU path yet");

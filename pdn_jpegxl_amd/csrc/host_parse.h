@@ -136,6 +136,7 @@ struct ParsedFrame {
   uint64_t hf_start_bits = 0;          // single-section frames: bit position right after HfGlobal (set by the LF pre-pass)
   // ---- HfGlobal
   bool dq_default = true;
+  std::vector<float> custom_dq[kNumQuantTables];   // !dq_default: 3 * n multipliers (1 / weight) per table, stored layout
   uint32_t num_presets = 1;
   std::vector<uint16_t> custom_order[kNumOrders][3];  // empty => natural
   HostCode acode;

@@ -200,3 +200,49 @@ def test_single_group_frames(oracle, size, kw, layout):
     assert d.max() <= 1 and (d > 0).mean() <= 0.01
     if layout == "rgba":
         assert (got.pixels[..., 3] == img[..., 3]).all()
+
+
+# ---------------------------------------------------------------- entropy-coding variants and explicit quantisation tables (row a7)
+@pytest.mark.parametrize("opts", [dict(prefix_codes=True), dict(lz77=True), dict(prefix_codes=True, lz77=True)], ids=["prefix", "lz77", "prefix+lz77"])
+def test_prefix_coded_and_lz77_streams(gpu_decoder, oracle, opts):
+    """Every section stream (LF, HF metadata, HF coefficients, alpha) written with prefix codes instead of ANS and / or LZ77 (runs and
+    copies from one row up, so both the plain and the special two-dimensional distances occur): same stage-by-stage parity bar."""
+    img = synth(640, 520, 71)
+    img[40:200, 50:500, 3] = 255             # long runs in the alpha stream
+    img[300:360, :, :] = img[300:301, :, :]  # repeated rows: copies at distance = channel width
+    run_case(gpu_decoder, oracle, img, **opts)
+
+
+@pytest.mark.parametrize("opts", [dict(prefix_codes=True), dict(lz77=True), dict(prefix_codes=True, lz77=True)], ids=["prefix", "lz77", "prefix+lz77"])
+@pytest.mark.parametrize("squeeze", [False, True])
+def test_prefix_coded_and_lz77_lossless(gpu_decoder, oracle, opts, squeeze):
+    img = synth(600, 540, 72)
+    img[100:180, 60:400, :] = img[100:101, 60:61, :]   # a flat rectangle
+    img[300:340, :, :] = img[300:301, :, :]
+    data = oracle.encode(img, lossless=True, lossless_squeeze=squeeze, **opts)
+    out = gpu_decode(gpu_decoder, [data])[0]
+    assert (out == img).all()
+
+
+def test_explicit_quantisation_tables(gpu_decoder, oracle):
+    """All seventeen dequantisation tables signalled explicitly (identity / DCT2 / DCT4 / DCT4x8 / distance-band encodings with scaled
+    parameters), every transform in use: the weights come from the stream, not from the library defaults."""
+    data, od = run_case(gpu_decoder, oracle, synth(776, 520, 73), strategy_mode=2, seed=11, custom_quant_tables=True)
+    plain = oracle.decode(oracle.encode(synth(776, 520, 73), strategy_mode=2, seed=11)).pixels
+    assert (plain != od.pixels).mean() > 0.05      # the tables really differ from the defaults
+
+
+def test_corrupt_prefix_and_lz77_streams_fail_cleanly(gpu_decoder, oracle):
+    img = synth(520, 300, 74)
+    data = bytearray(oracle.encode(img, prefix_codes=True, lz77=True))
+    rng = np.random.default_rng(3)
+    bad = 0
+    for k in range(12):
+        d = bytearray(data)
+        for p in rng.integers(len(d) // 3, len(d), 6):
+            d[p] ^= 1 << int(rng.integers(0, 8))
+        try:
+            gpu_decode(gpu_decoder, [bytes(d)])
+        except (api.FormatError, AssertionError):
+            bad += 1
+    assert bad >= 6   # most corruptions are detected (final states, ranges); none may crash or hang

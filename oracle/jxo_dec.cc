@@ -74,6 +74,7 @@ struct FrameDecoder {
   uint32_t num_presets = 1;
   std::vector<uint32_t> order[8][kNumOrders][3];  // per pass; empty => natural
   EntropyCode hf_code[8];
+  std::vector<std::vector<int32_t>> qacc[3];   // multi-pass frames: per origin cell, the quantised block accumulated so far
   // pixels
   Plane xyb[3];
   std::vector<int32_t> qcoef[3];
@@ -299,7 +300,8 @@ struct FrameDecoder {
     int gx = g % f.xsize_groups, gy = g / f.xsize_groups;
     if (f.encoding == 0) DecodeAcGroup(br, gx, gy, pass);
     int min_shift = 0, max_shift = 2;
-    JXO_CHECK(f.num_passes == 1, "multi-pass modular groups are not supported");
+    // without downsampling brackets every Modular channel of the group belongs to the last pass (earlier passes hold none)
+    if (pass + 1 != f.num_passes) return;
     uint32_t sid = 1 + 3 * f.num_lf_groups + kNumQuantTables + f.num_groups * pass + g;
     DecodeModularGroup(br, gx * f.group_dim, gy * f.group_dim, f.group_dim, f.group_dim, min_shift, max_shift, sid);
     JXO_CHECK(!br.overrun, "truncated PassGroup");
@@ -327,7 +329,15 @@ struct FrameDecoder {
         int cx = kCoveredX[s], cy = kCoveredY[s];
         uint32_t covered = cx * cy, log2c = CeilLog2(covered), size = covered * 64;
         uint32_t ord = kStrategyOrder[s];
-        for (int c = 0; c < 3; c++) q[c].assign(size, 0);
+        // several passes: the quantised values add up over the passes (each shifted by its pass's shift), kept per varblock
+        for (int c = 0; c < 3; c++) {
+          if (f.num_passes == 1) q[c].assign(size, 0);
+          else {
+            std::vector<int32_t>& acc = qacc[c][cell];
+            if (acc.empty()) acc.assign(size, 0);
+            q[c] = acc;
+          }
+        }
         for (int c : {1, 0, 2}) {
           uint32_t predicted;
           {
@@ -356,7 +366,8 @@ struct FrameDecoder {
           }
           JXO_CHECK(nzeros == 0, "nonzero count mismatch");
         }
-        ReconstructBlock(s, bx0 + bx, by0 + by, q, coef, pix);
+        if (pass + 1 == f.num_passes) ReconstructBlock(s, bx0 + bx, by0 + by, q, coef, pix);
+        else for (int c = 0; c < 3; c++) qacc[c][cell] = q[c];
         JXO_CHECK(!br.overrun, "truncated AC group");
       }
     }
@@ -534,7 +545,8 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
             "first frame is not a regular frame (LF / reference frames are not supported)");
   JXO_CHECK(!f.have_crop && f.upsampling == 1, "cropped / upsampled frames are not supported");
   JXO_CHECK(!f.do_ycbcr, "YCbCr frames are not supported");
-  JXO_CHECK(f.num_passes == 1, "multi-pass frames are not supported yet");
+  JXO_CHECK(f.num_passes <= 8, "too many passes");
+  if (f.encoding == 1) JXO_CHECK(f.num_passes == 1, "multi-pass Modular frames are not supported yet");
   if (f.encoding == 0) JXO_CHECK(m.xyb_encoded, "VarDCT without XYB is not supported");
   if (f.encoding == 1) JXO_CHECK(!m.xyb_encoded, "Modular XYB frames are not supported yet");
   Toc toc;
@@ -600,10 +612,12 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
       BitReader sr = section(1 + f.num_lf_groups);
       d.ReadHfGlobal(sr);
     }
-    ParallelFor((int)f.num_groups, opt.num_threads, [&](int g) {
-      BitReader sr = section(2 + f.num_lf_groups + g);
-      d.ReadPassGroup(sr, g, 0);
-    });
+    if (f.num_passes > 1) for (int c = 0; c < 3; c++) d.qacc[c].assign(ncell, std::vector<int32_t>());
+    for (uint32_t pass = 0; pass < f.num_passes; pass++)
+      ParallelFor((int)f.num_groups, opt.num_threads, [&](int g) {
+        BitReader sr = section(2 + f.num_lf_groups + pass * f.num_groups + g);
+        d.ReadPassGroup(sr, g, pass);
+      });
   }
   UndoTransforms(d.full);
 

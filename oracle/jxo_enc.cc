@@ -378,7 +378,11 @@ struct VarDctEncoder {
     const uint32_t nlf = f.num_lf_groups, ng = f.num_groups;
     Tree tree = MakeVarDctTree(nlf);
     WPHeader wp_default;
-    std::vector<std::vector<Token>> lf_tok(nlf), meta_tok(nlf), alpha_tok(ng), ac_tok(ng);
+    const uint32_t np = (uint32_t)std::max(1, std::min(3, p.num_passes));
+    f.num_passes = np;
+    if (np == 2) f.pass_shift[0] = 1;
+    if (np == 3) { f.pass_shift[0] = 2; f.pass_shift[1] = 1; }
+    std::vector<std::vector<Token>> lf_tok(nlf), meta_tok(nlf), alpha_tok(ng), ac_tok((size_t)ng * np);
     std::vector<uint32_t> nb_blocks(nlf);
     ParallelFor((int)nlf, p.num_threads, [&](int g) {
       int gx = g % f.xsize_lf_groups, gy = g / f.xsize_lf_groups;
@@ -417,9 +421,15 @@ struct VarDctEncoder {
       // AC tokens
       const int bx0 = gx * 32, by0 = gy * 32;
       const int bw = std::min(32, w8 - bx0), bh = std::min(32, h8 - by0);
+      for (uint32_t pass = 0; pass < np; pass++) {
       uint8_t nz[3][32 * 32];
       memset(nz, 0, sizeof(nz));
-      std::vector<Token>& out = ac_tok[g];
+      std::vector<Token>& out = ac_tok[(size_t)pass * ng + g];
+      // this pass's share of a quantised value: what is left after the earlier passes, shifted down by the pass's shift
+      auto share = [&](int32_t v) {
+        for (uint32_t k = 0; k < pass; k++) v -= (v >> f.pass_shift[k]) << f.pass_shift[k];
+        return pass + 1 < np ? v >> f.pass_shift[pass] : v;
+      };
       for (int by = 0; by < bh; by++)
         for (int bx = 0; bx < bw; bx++) {
           size_t cell = (size_t)(by0 + by) * w8 + bx0 + bx;
@@ -429,7 +439,8 @@ struct VarDctEncoder {
           uint32_t ord = kStrategyOrder[s];
           const uint32_t* ordp = NaturalOrder(s).data();
           for (int c : {1, 0, 2}) {
-            const std::vector<int32_t>& q = qac[c][cell];
+            std::vector<int32_t> q = qac[c][cell];
+            if (np > 1) for (auto& v : q) v = share(v);
             uint32_t nzeros = 0;
             for (uint32_t k = covered; k < size; k++) nzeros += q[ordp[k]] != 0;
             uint32_t predicted;
@@ -453,6 +464,7 @@ struct VarDctEncoder {
             }
           }
         }
+      }
       // alpha tokens
       if (has_alpha) {
         int x0 = gx * f.group_dim, y0 = gy * f.group_dim;
@@ -468,7 +480,7 @@ struct VarDctEncoder {
     // 6. write sections
     const bool single = f.NumTocEntries() == 1;
     const bool alpha_global = has_alpha && w <= (int)f.group_dim && h <= (int)f.group_dim;
-    std::vector<BitWriter> sec(single ? 4 : 2 + nlf + ng);
+    std::vector<BitWriter> sec(single ? 4 : 2 + nlf + (size_t)ng * np);
     // --- LfGlobal
     BitWriter& g0 = sec[0];
     g0.Bool(true);  // LF dequant defaults
@@ -523,21 +535,25 @@ struct VarDctEncoder {
     else hg.Bool(true);                     // default dequant matrices
     hg.Write(CeilLog2(ng), 0);              // num_hf_presets - 1
     hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);  // used_orders: none
-    std::vector<const std::vector<Token>*> acsets;
-    for (auto& t : ac_tok) acsets.push_back(&t);
-    EncOptions ao;
-    ao.max_clusters = 96;
-    EncCode acode;
-    BuildAndWriteCode(acsets, bctx.NumAcContexts(), ao, hg, acode);
-    // --- PassGroups
-    for (uint32_t g = 0; g < ng; g++) {
-      BitWriter& s = sec[2 + nlf + g];
-      WriteTokens(ac_tok[g], acode, s);
-      if (has_alpha && !alpha_global) {
-        WriteGroupHeader(s, gh);
-        WriteTokens(alpha_tok[g], mcode, s);
-      }
+    std::vector<EncCode> acode(np);
+    for (uint32_t pass = 0; pass < np; pass++) {
+      if (pass) hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);   // every pass: its coefficient orders (none), then its code
+      std::vector<const std::vector<Token>*> acsets;
+      for (uint32_t g = 0; g < ng; g++) acsets.push_back(&ac_tok[(size_t)pass * ng + g]);
+      EncOptions ao;
+      ao.max_clusters = 96;
+      BuildAndWriteCode(acsets, bctx.NumAcContexts(), ao, hg, acode[pass]);
     }
+    // --- PassGroups
+    for (uint32_t pass = 0; pass < np; pass++)
+      for (uint32_t g = 0; g < ng; g++) {
+        BitWriter& s = sec[single ? 3 : 2 + nlf + (size_t)pass * ng + g];
+        WriteTokens(ac_tok[(size_t)pass * ng + g], acode[pass], s);
+        if (pass + 1 == np && has_alpha && !alpha_global) {
+          WriteGroupHeader(s, gh);
+          WriteTokens(alpha_tok[g], mcode, s);
+        }
+      }
     return AssembleFrame(m, f, sec);
   }
 };
@@ -696,6 +712,7 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
       src = other.data();
     }
     FrameHeader f;
+    ClearStreamDistMults();
     f.ec_upsampling.assign(m.ec.size(), 1);
     f.is_last = k + 1 == std::max(1, p.animation_frames);
     f.duration = m.have_animation ? 10 : 0;
@@ -718,6 +735,7 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
       one = enc.Encode(src, nch);
     }
     frame.insert(frame.end(), one.begin(), one.end());
+    ClearStreamDistMults();
   }
   BitWriter bw;
   bw.Write(8, 0xFF);

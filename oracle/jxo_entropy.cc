@@ -559,6 +559,12 @@ void SetStreamDistMult(const std::vector<Token>* tokens, uint32_t dist_mult) {
   std::lock_guard<std::mutex> lock(g_dm_mutex);
   if (dist_mult) g_dist_mult[tokens] = dist_mult; else g_dist_mult.erase(tokens);
 }
+// The registry is keyed by the address of a token vector: entries must not outlive the frame that made them, or a later vector at
+// the same address (say, an HF coefficient stream, which has no multiplier) inherits a stale one and the stream no longer decodes.
+void ClearStreamDistMults() {
+  std::lock_guard<std::mutex> lock(g_dm_mutex);
+  g_dist_mult.clear();
+}
 static uint32_t StreamDistMult(const void* tokens) {
   std::lock_guard<std::mutex> lock(g_dm_mutex);
   auto it = g_dist_mult.find(tokens);

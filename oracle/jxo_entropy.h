@@ -131,5 +131,6 @@ void WriteTokens(const std::vector<Token>& tokens, const EncCode& ec, BitWriter&
 // coefficients; Modular streams: the largest channel width of the sub-image).  Registered per token vector (by address) before the
 // code is built, because the choice of copies - hence the histograms - depends on it.
 void SetStreamDistMult(const std::vector<Token>* tokens, uint32_t dist_mult);
+void ClearStreamDistMults();   // at every frame boundary of the encoder
 
 }  // namespace jxo

@@ -112,6 +112,15 @@ static const float kDefaultOpsinInverse[9] = {11.031566901960783f, -9.8669439215
                                               -3.254147380392157f, 4.418770392156863f,  -0.16462299647058826f,
                                               -3.6588512862745097f, 2.7129230470588235f, 1.9459282392156863f};
 
+void ImageMetadata::SetDefaultTransformData() {
+  memcpy(opsin_inverse, kDefaultOpsinInverse, sizeof(kDefaultOpsinInverse));
+  for (int i = 0; i < 3; i++) opsin_bias[i] = -0.0037930732552754493f;
+  quant_bias[0] = 1.0f - 0.05465007330715401f;
+  quant_bias[1] = 1.0f - 0.07005449891748593f;
+  quant_bias[2] = 1.0f - 0.049935103337343655f;
+  quant_bias[3] = 0.145f;
+}
+
 void ReadImageMetadata(BitReader& br, ImageMetadata& m) {
   bool all_default = br.Bool();
   bool extra_fields = false;
@@ -167,12 +176,7 @@ void ReadImageMetadata(BitReader& br, ImageMetadata& m) {
     }
   }
   // custom transform data
-  memcpy(m.opsin_inverse, kDefaultOpsinInverse, sizeof(kDefaultOpsinInverse));
-  for (int i = 0; i < 3; i++) m.opsin_bias[i] = -0.0037930732552754493f;
-  m.quant_bias[0] = 1.0f - 0.05465007330715401f;
-  m.quant_bias[1] = 1.0f - 0.07005449891748593f;
-  m.quant_bias[2] = 1.0f - 0.049935103337343655f;
-  m.quant_bias[3] = 0.145f;
+  m.SetDefaultTransformData();
   m.default_transform = br.Bool();
   if (!m.default_transform) {
     if (m.xyb_encoded) {
@@ -382,7 +386,7 @@ void WriteFrameHeader(BitWriter& bw, const ImageMetadata& m, const FrameHeader& 
                      f.name.empty() && lf_default && !m.have_animation;
   bw.Bool(all_default);
   if (all_default) return;
-  JXO_CHECK(f.frame_type == 0 && !f.have_crop && f.num_passes == 1 && f.upsampling == 1 && (f.is_last || m.have_animation),
+  JXO_CHECK(f.frame_type == 0 && !f.have_crop && f.num_passes >= 1 && f.num_passes <= 3 && f.upsampling == 1 && (f.is_last || m.have_animation),
             "oracle encoder writes regular full frames (several only as an animation)");
   bw.Write(2, f.frame_type);
   bw.Write(1, f.encoding);
@@ -395,7 +399,11 @@ void WriteFrameHeader(BitWriter& bw, const ImageMetadata& m, const FrameHeader& 
   }
   if (f.encoding == 1) bw.Write(2, f.group_size_shift);
   if (f.encoding == 0 && m.xyb_encoded) { bw.Write(3, f.x_qm_scale); bw.Write(3, f.b_qm_scale); }
-  bw.U32(Val(1), Val(2), Val(3), BitsOff(3, 4), 1);  // passes
+  bw.U32(Val(1), Val(2), Val(3), BitsOff(3, 4), f.num_passes);
+  if (f.num_passes != 1) {
+    bw.U32(Val(0), Val(1), Val(2), BitsOff(1, 3), 0);   // no downsampling brackets: everything Modular goes to the last pass
+    for (uint32_t i = 0; i + 1 < f.num_passes; i++) bw.Write(2, f.pass_shift[i]);
+  }
   bw.Bool(false);                                    // have_crop
   // blending info (replace), full frame => no source field
   bw.U32(Val(0), Val(1), Val(2), BitsOff(2, 3), 0);

@@ -45,6 +45,8 @@ struct ImageMetadata {
   float opsin_inverse[9];
   float opsin_bias[3];
   float quant_bias[4];
+  ImageMetadata() { SetDefaultTransformData(); }
+  void SetDefaultTransformData();   // what a stream with default_transform = true implies (the encoder's quantiser reads quant_bias too)
   int alpha_index() const {
     for (size_t i = 0; i < ec.size(); i++) if (ec[i].type == 0) return (int)i;
     return -1;

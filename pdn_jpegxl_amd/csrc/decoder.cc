@@ -378,8 +378,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // images that failed to parse are skipped on the device (their DevImage stays zeroed, ng = 0)
   // ---- 2. layout of blob and workspace
   Bump blob, ws_zero, ws;
-  const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)n);
+  // every pass after the first of a progressive frame is an image record of its own, after the batch's n (dev_types.h: next_pass)
+  int n_extra = 0;
+  std::vector<int> first_extra((size_t)n, 0);
+  for (int i = 0; i < n; i++) {
+    first_extra[i] = n + n_extra;
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_extra += (int)frames[i].extra_passes.size();
+  }
+  const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)(n + n_extra));
+  struct PassLayout {   // what a pass owns: its code, scan lists, entry lists, block index, end positions, LZ77 windows
+    size_t a_cmap, a_cfg, a_alias, a_pfx[3] = {}, lz_hf = 0, scan[kNumQuantTables] = {}, centries, cblk, bitpos;
+  };
   struct PerImg {
+    std::vector<PassLayout> extra;
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t m_pfx[3] = {}, a_pfx[3] = {};           // prefix codes: counts, symbol offsets, sorted symbols
     size_t lz_lf = 0, lz_grp = 0, lz_hf = 0, lz_mod = 0;   // LZ77 windows (+1; 0: none)
@@ -462,6 +473,22 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       const int g0 = std::max(0, b0 - 1), g1 = std::min<int>((int)f.yg, b1 + 1);
       l.centries = ws.Take((size_t)std::max(1, g1 - g0) * f.xg * kGroupEntriesCap * 4);
       l.cblk = ws.Take(3 * cells * sizeof(U32x2));
+      for (auto& ep : f.extra_passes) {
+        PassLayout pl;
+        pl.a_cmap = blob.Take(ep.acode.ctx_map.size());
+        pl.a_cfg = blob.Take(4 * ep.acode.cfg.size());
+        pl.a_alias = blob.Take(8 * ep.acode.alias.size());
+        pfx_layout(ep.acode, pl.a_pfx);
+        if (ep.acode.lz77) pl.lz_hf = ws.Take((size_t)f.ng * ((size_t)4 << 18)) + 1;
+        for (int q = 0; q < kNumQuantTables; q++) {
+          const int o = OrderBucketOfQuantTable(q);
+          if (l.dq[q] || !ep.custom_order[o][0].empty() || !ep.custom_order[o][1].empty() || !ep.custom_order[o][2].empty()) pl.scan[q] = blob.Take(8 * 3 * (size_t)dq_n[q], 256) + 1;
+        }
+        pl.centries = ws.Take((size_t)std::max(1, g1 - g0) * f.xg * kGroupEntriesCap * 4);
+        pl.cblk = ws.Take(3 * cells * sizeof(U32x2));
+        pl.bitpos = ws.Take((size_t)f.ng * 8);
+        l.extra.push_back(pl);
+      }
     }
     for (int c = 0; c < 3; c++) { l.lf[c] = ws.Take(4 * cells); l.lf_tmp[c] = ws.Take(4 * cells); l.lfq[c] = ws.Take(4 * cells); }
     l.lf_extra = ws.Take(f.nlf);
@@ -484,7 +511,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.lf_end = ws.Take(8);
     if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
     total_lf += f.nlf;
-    total_groups += f.ng;
+    total_groups += f.ng * f.num_passes;
   }
   // The float planes between reconstruction and the loop filters (24 B/px) are only alive while a frame is in the pixel stages:
   // frames go through those stages in chunks that share kPixelChunk sets of planes, so the batch size is bounded by the
@@ -543,7 +570,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // width) plus 288 B per lane, and a launch has ONE LDS size.  Sized by the batch-wide maximum, a single image with wide tables
   // pushed every workgroup from two per CU to one (hf_decode 30 -> 58 ms at batch 384); instead every image gets as many lanes per
   // workgroup as fit beside ITS tables in half a CU's LDS (whole wavefronts; images with wide tables use more, smaller workgroups).
-  auto hf_table_bytes = [](const ParsedFrame& f) { return 8 + 8 * f.acode.alias.size() + 4 * f.acode.cfg.size() + f.acode.ctx_map.size() + 64 + 32; };
+  auto hf_code_bytes = [](const HostCode& c) { return 8 + 8 * c.alias.size() + 4 * c.cfg.size() + c.ctx_map.size() + 64 + 32; };
+  auto hf_table_bytes = [&](const ParsedFrame& f) {   // the widest of the frame's passes
+    size_t b = hf_code_bytes(f.acode);
+    for (auto& ep : f.extra_passes) b = std::max(b, hf_code_bytes(ep.acode));
+    return b;
+  };
   const size_t kHfLdsTarget = 80 * 1024;
   auto hf_per_wg = [&](const ParsedFrame& f) {
     const int per_wave = 64 / lane_stride;
@@ -553,7 +585,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   };
   int n_pass_wg = 0;
   for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_pass_wg += ((int)frames[i].ng + hf_per_wg(frames[i]) - 1) / hf_per_wg(frames[i]);
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0)
+      n_pass_wg += (int)frames[i].num_passes * (((int)frames[i].ng + hf_per_wg(frames[i]) - 1) / hf_per_wg(frames[i]));
   const size_t off_lf_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, total_lf));
   const size_t off_pass_tasks = blob.Take(sizeof(SectionTask) * (size_t)std::max(1, n_pass_wg));
   // Lane mapping of the alpha phase-A kernel (one wavefront per workgroup, sections of one image per wavefront): spread the
@@ -595,7 +628,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   // ---- 3. fill the pinned blob
   memset(h_blob, 0, blob.off);
-  imgs.assign(n, DevImage());
+  imgs.assign(n + n_extra, DevImage());
+  for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
   bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
@@ -821,10 +855,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.inv_sigma = (float*)(wr + l.inv_sigma);
     d.alpha = wr + l.alpha;
     d.lf_end_bits = (uint64_t*)(wr + l.lf_end);
+    // a frame of one group has its alpha channel in LfGlobal (channels no larger than a group are coded globally)
+    d.alpha_in_global = (d.has_alpha && f.ng == 1) ? 1 : 0;
+    d.lf_start_bits = f.after_lf_global_bits;
     if (f.single) {
       d.single = 1;
-      d.alpha_in_global = d.has_alpha;
-      d.lf_start_bits = f.after_lf_global_bits;
       d.hf_start_bits = f.hf_start_bits;
     }
     if (f.tree_uses_wp) { d.wp_lf = (int32_t*)(wr + l.wp_lf); d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * (kGroupDim + 2); }
@@ -868,15 +903,56 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (uint32_t g = l0; g < l1; g += lf_per_wave)
         lf_ans_tasks[nlf_ans_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>((uint32_t)lf_per_wave, l1 - g), 0};
     }
+    // progressive frames: one record per further pass, chained from this one
+    d.num_passes = (int32_t)f.num_passes;
+    d.pass_shift = (int32_t)f.pass_shift[0];
+    d.hf_sec_base = 2 + (int32_t)f.nlf;
+    d.alpha_sec_base = 2 + (int32_t)f.nlf + (int32_t)((f.num_passes - 1) * f.ng);   // the Modular streams of all shifts below 3 are in the last pass
+    d.alpha_bitpos = d.grp_bitpos;
+    d.next_pass = nullptr;
+    for (size_t p = 0; p < f.extra_passes.size(); p++) {
+      const ParsedFrame::PassCodes& ep = f.extra_passes[p];
+      const PassLayout& pl = l.extra[p];
+      DevImage& sh = imgs[(size_t)first_extra[i] + p];
+      sh = d;
+      memset(&sh.acode, 0, sizeof(sh.acode));
+      code(ep.acode, pl.a_cmap, pl.a_cfg, pl.a_alias, sh.acode, pl.a_pfx);
+      sh.lz_hf = pl.lz_hf ? (uint32_t*)(wr + pl.lz_hf - 1) : nullptr;
+      for (int q = 0; q < kNumQuantTables; q++) {
+        sh.scan[q] = d_scan[q];
+        if (pl.scan[q]) {
+          std::vector<U32x2> sl;
+          BuildScanList(q, ep.custom_order, sl, l.dq[q] ? &f.custom_dq[q] : nullptr);
+          put(pl.scan[q] - 1, sl.data(), sl.size() * sizeof(U32x2));
+          sh.scan[q] = (const U32x2*)(d_blob + pl.scan[q] - 1);
+        }
+      }
+      sh.centries = (uint32_t*)(wr + pl.centries);
+      sh.cblk = (U32x2*)(wr + pl.cblk);
+      sh.grp_bitpos = (uint64_t*)(wr + pl.bitpos);
+      sh.pass_shift = p + 1 < f.num_passes - 1 ? (int32_t)f.pass_shift[p + 1] : 0;
+      sh.hf_sec_base = 2 + (int32_t)f.nlf + (int32_t)((p + 1) * f.ng);
+      sh.next_pass = nullptr;
+      d.alpha_bitpos = sh.grp_bitpos;
+    }
+    {
+      const DevImage* d_recs = (const DevImage*)(d_blob + off_imgs);
+      for (size_t p = 0; p < f.extra_passes.size(); p++) {
+        DevImage& prev = p ? imgs[(size_t)first_extra[i] + p - 1] : d;
+        prev.next_pass = d_recs + first_extra[i] + p;
+        imgs[(size_t)first_extra[i] + p].alpha_bitpos = d.alpha_bitpos;
+      }
+    }
     const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
     const uint32_t pw = (uint32_t)hf_per_wg(f);
-    for (uint32_t g = hg0; g < hg1; g += pw) {
-      const uint32_t cnt = std::min<uint32_t>(pw, hg1 - g);
-      pass_tasks[npass_t++] = SectionTask{i, (int32_t)g, (int32_t)cnt, 0};
-      const size_t lanes = (size_t)((cnt + 3) & ~3u) * HfLaneLdsBytes(32);   // the kernel lays its per-lane arrays out for the task's lanes
-      lds_hf = std::max(lds_hf, hf_table_bytes(f) + lanes);
-      lds_hf_lanes = std::max(lds_hf_lanes, lanes);
-    }
+    for (uint32_t pass = 0; pass < f.num_passes; pass++)
+      for (uint32_t g = hg0; g < hg1; g += pw) {
+        const uint32_t cnt = std::min<uint32_t>(pw, hg1 - g);
+        pass_tasks[npass_t++] = SectionTask{pass ? first_extra[i] + (int)pass - 1 : i, (int32_t)g, (int32_t)cnt, 0};
+        const size_t lanes = (size_t)((cnt + 3) & ~3u) * HfLaneLdsBytes(32);   // the kernel lays its per-lane arrays out for the task's lanes
+        lds_hf = std::max(lds_hf, hf_table_bytes(f) + lanes);
+        lds_hf_lanes = std::max(lds_hf_lanes, lanes);
+      }
     const uint32_t ag0 = (uint32_t)(d.band_y0 / kGroupDim) * f.xg, ag1 = (uint32_t)((d.band_y1 + kGroupDim - 1) / kGroupDim) * f.xg;
     if (d.has_alpha)
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
@@ -884,7 +960,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   const int hf_ring = 32;   // words of the per-lane bit window
   const size_t kLdsMax = 150 * 1024;
-  memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * (size_t)n);
+  memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * imgs.size());
   d_imgs = (DevImage*)(d_blob + off_imgs);
   // ---- 4. enqueue: LF chain on s_lf, everything that needs the block layout on the main stream
   stage_names.clear();

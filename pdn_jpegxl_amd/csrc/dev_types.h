@@ -138,6 +138,12 @@ struct DevImage {
   uint32_t* blk_list;       // per group: 1024 x 2 words, varblocks in decode order (hf_blocklist_kernel)
   uint32_t* blk_count;      // per group
   uint64_t* grp_bitpos;     // per group: codestream bit position after the HF tokens (~0 = failed)
+  // Progressive frames: every pass after the first is a record of its own after the batch's images (same block layout, its own code,
+  // coefficient orders, entry lists and sections); next_pass chains them.  The alpha stream follows the HF tokens of the LAST pass.
+  int32_t num_passes, pass_shift;          // this record's pass contributes value << pass_shift
+  int32_t hf_sec_base, alpha_sec_base;     // TOC entry of group 0 of this pass / of the pass that holds the Modular streams
+  const DevImage* next_pass;
+  const uint64_t* alpha_bitpos;            // grp_bitpos of the last pass
   // single-section frames (they fit one group): the sections share one bit stream
   int32_t single, alpha_in_global;
   uint64_t lf_start_bits;   // where the GPU starts (global alpha channel, then the LF group)

@@ -923,17 +923,22 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   const int lf_sec = im.single ? 0 : 1 + g;
   const uint64_t start_bits = im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8;
   LaneBits b;
-  b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
+  b.Init(im.cs, im.cs_size, im.alpha_in_global ? im.lf_start_bits : start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
   uint32_t state = 0, err = 0, count = 1;
   int32_t* const wps = im.wp_lf ? im.wp_lf + (size_t)g * kWpLfInts : nullptr;
   uint32_t* const lzw = im.lz_lf ? im.lz_lf + ((size_t)g << 20) : nullptr;   // LZ77 window of this lane's streams
-  if (im.single && im.alpha_in_global) {
-    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0)
+  if (im.alpha_in_global) {
+    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0), which the LF group
+    // follows directly (one-section frames) or in a section of its own (progressive frames: one section per pass)
     b.SetLz(lzw, 20, (uint32_t)im.w);
     b.lz_copy = 0; b.lz_done = 0;
     state = InitAnsState(b, mt.tab);
     DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc, wps);
-    if (state != 0x130000u) err |= kErrBitstream;
+    if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
+    if (!im.single) {
+      if (im.lf_start_bits + b.Consumed() > (im.sec_off[0] + im.sec_size[0]) * 8) err |= kErrBitstream;
+      b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
+    }
   }
   if (!err) {
     im.lf_extra[g] = (uint8_t)b.Read(2);
@@ -1197,7 +1202,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   if (si >= task.count || si >= nslots) return;
   JXL_LDS uint8_t* const col = nzcol + si;   // col[(c * 32 + x) * nslots]
   const int g = task.first + si;
-  const int sec = im.single ? 0 : 2 + im.nlf + g;
+  const int sec = im.single ? 0 : im.hf_sec_base + g;
   const uint64_t sec_bits = im.single ? im.hf_start_bits : im.sec_off[sec] * 8;
   Bits b;
   b.Init(im.cs, im.cs_size, sec_bits, ring_base + si, (uint32_t)nslots);
@@ -1368,7 +1373,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
   if (lane >= 64 / lane_stride || lane >= task.count) return;
   const int g = task.first + lane;
   ChanDesc* desc = im.alpha_desc + g;
-  const uint64_t start = im.grp_bitpos[g];
+  const uint64_t start = im.alpha_bitpos[g];
   if (start == ~(uint64_t)0) {   // the HF decoder already reported the failure
     ChanDesc d;
     d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
@@ -1376,7 +1381,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
     return;
   }
   const int gx = g % im.xg, gy = g / im.xg;
-  const int sec = 2 + im.nlf + g;
+  const int sec = im.alpha_sec_base + g;
   LaneBits b;
   b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
   uint32_t err = 0;

@@ -581,9 +581,12 @@ void ReadFrameHeader(Bits& r, ParsedFrame& f) {
       f.num_passes = r.U32(V(1), V(2), V(3), B(3, 4));
       if (f.num_passes != 1) {
         uint32_t nds = r.U32(V(0), V(1), V(2), B(1, 3));
-        r.Skip(2 * (f.num_passes - 1));
+        REQUIRE(f.num_passes <= 8, "too many passes");
+        for (uint32_t i = 0; i + 1 < f.num_passes; i++) f.pass_shift[i] = r.u(2);
         for (uint32_t i = 0; i < nds; i++) r.U32(V(1), V(2), V(4), V(8));
         for (uint32_t i = 0; i < nds; i++) r.U32(V(0), V(1), V(2), B(3));
+        // downsampling brackets move squeezed Modular channels into earlier passes; without them everything Modular is in the last pass
+        REQUIRE(nds == 0, "progressive frames with downsampling brackets are not supported yet");
       }
     }
     if (f.frame_type == 1) r.U32(V(1), V(2), V(3), V(4));
@@ -1086,28 +1089,33 @@ void ReadHfGlobal(Bits& r, ParsedFrame& f, std::vector<float> custom_dq[kNumQuan
     }
   }
   f.num_presets = 1 + r.u(CeilLog2(f.ng));
-  REQUIRE(f.num_passes == 1, "multi-pass frames are not supported yet");
-  uint32_t used = r.U32(V(0x5F), V(0x13), V(0), B(kNumOrders));
-  if (used) {
-    HostCode c;
-    ReadCode(r, 8, c);
-    SymReader sr(c, r);
-    const StaticTables& st = GetStaticTables();
-    for (int o = 0; o < kNumOrders; o++) {
-      if (!(used >> o & 1)) continue;
-      const std::vector<uint16_t>& nat = st.natural_order[o];
-      int s = kBucketStrategy[o];
-      size_t llf = (size_t)kCoveredX[s] * kCoveredY[s];
-      for (int ch = 0; ch < 3; ch++) {
-        std::vector<uint32_t> perm;
-        ReadPermutation(sr, llf, nat.size(), perm);
-        f.custom_order[o][ch].resize(nat.size());
-        for (size_t k = 0; k < nat.size(); k++) f.custom_order[o][ch][k] = nat[perm[k]];
+  REQUIRE(f.encoding == 0 || f.num_passes == 1, "multi-pass Modular frames are not supported yet");
+  f.extra_passes.assign(f.num_passes - 1, ParsedFrame::PassCodes());
+  for (uint32_t pass = 0; pass < f.num_passes; pass++) {
+    std::vector<uint16_t> (*orders)[3] = pass ? f.extra_passes[pass - 1].custom_order : f.custom_order;
+    HostCode& acode = pass ? f.extra_passes[pass - 1].acode : f.acode;
+    uint32_t used = r.U32(V(0x5F), V(0x13), V(0), B(kNumOrders));
+    if (used) {
+      HostCode c;
+      ReadCode(r, 8, c);
+      SymReader sr(c, r);
+      const StaticTables& st = GetStaticTables();
+      for (int o = 0; o < kNumOrders; o++) {
+        if (!(used >> o & 1)) continue;
+        const std::vector<uint16_t>& nat = st.natural_order[o];
+        int s = kBucketStrategy[o];
+        size_t llf = (size_t)kCoveredX[s] * kCoveredY[s];
+        for (int ch = 0; ch < 3; ch++) {
+          std::vector<uint32_t> perm;
+          ReadPermutation(sr, llf, nat.size(), perm);
+          orders[o][ch].resize(nat.size());
+          for (size_t k = 0; k < nat.size(); k++) orders[o][ch][k] = nat[perm[k]];
+        }
       }
+      REQUIRE(sr.Final(), "coefficient orders: ANS final state");
     }
-    REQUIRE(sr.Final(), "coefficient orders: ANS final state");
+    ReadCode(r, (size_t)f.num_presets * f.num_block_ctx * 495, acode);
   }
-  ReadCode(r, (size_t)f.num_presets * f.num_block_ctx * 495, f.acode);
   REQUIRE(r.ok(), "truncated HfGlobal");
 }
 

@@ -140,6 +140,14 @@ struct ParsedFrame {
   uint32_t num_presets = 1;
   std::vector<uint16_t> custom_order[kNumOrders][3];  // empty => natural
   HostCode acode;
+  // Progressive frames: the coefficients arrive in num_passes instalments, pass p shifted left by pass_shift[p] (the last by 0);
+  // pass 0 uses custom_order / acode above, the later passes their own orders and codes
+  uint32_t pass_shift[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  struct PassCodes {
+    std::vector<uint16_t> custom_order[kNumOrders][3];
+    HostCode acode;
+  };
+  std::vector<PassCodes> extra_passes;
 };
 
 // Throws ParseError.  headers_only: stop after the frame header + TOC (jxlhip_peek / pass 1 of LoadImage).

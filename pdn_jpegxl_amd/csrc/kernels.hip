@@ -111,7 +111,6 @@ __global__ void expand_scatter_kernel(const DevImage* imgs, int all) {
   FOR_TILES(im, tile, all) {
     const int tx = tile % im.wt, ty = tile / im.wt;
     if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) continue;
-    const uint32_t* entries = im.centries + (size_t)((ty >> 2) * im.xg + (tx >> 2) - im.centries_g0) * kGroupEntriesCap;
     for (int pair = wave; pair < 192; pair += nwaves) {   // (cell, channel) pairs of the tile, one wavefront each
       const int cell = pair & 63, c = pair >> 6;
       const int bx = tx * 8 + (cell & 7), by = ty * 8 + (cell >> 3);
@@ -119,20 +118,30 @@ __global__ void expand_scatter_kernel(const DevImage* imgs, int all) {
       const uint32_t info = im.cellinfo[(size_t)by * im.w8 + bx];
       if (!(info >> 31) || (info & 0x3FF00u)) continue;   // not the origin cell of a varblock
       const uint32_t s = info & 0xFF, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
-      const U32x2 blk = im.cblk[(size_t)c * ncells + (size_t)by * im.w8 + bx];
-      if (blk.y > 65536u || blk.x > kGroupEntriesCap - blk.y) continue;   // left unwritten by a failed section
       const uint32_t q = c_quant_table[s], nq = im.dq_n[q];
-      const U32x2* scan = im.scan[q] + (size_t)c * nq;
       const uint32_t lng = 3 + max(lcx, lcy);
       const bool transposed = !IsSpecial(s) && lcy >= lcx;
       int32_t* plane = im.coef[c] + (size_t)by * 8 * im.wp + (size_t)bx * 8;
-      for (uint32_t i = lane; i < blk.y; i += 64) {
-        const uint32_t ent = entries[blk.x + i], k = ent & 0xFFFFu;
-        if (k >= nq) continue;
-        const uint32_t p = scan[k].x;
-        const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
-        const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
-        if (ky < (8u << lcy) && kx < (8u << lcx)) plane[(size_t)ky * im.wp + kx] = (int32_t)ent >> 16;
+      // every pass of a progressive frame adds its share (value << shift); each has its own lists, orders and scan lists
+      for (const DevImage* ps = &im; ps; ps = ps->next_pass) {
+        const uint32_t* entries = ps->centries + (size_t)((ty >> 2) * im.xg + (tx >> 2) - ps->centries_g0) * kGroupEntriesCap;
+        const U32x2 blk = ps->cblk[(size_t)c * ncells + (size_t)by * im.w8 + bx];
+        if (blk.y > 65536u || blk.x > kGroupEntriesCap - blk.y) continue;   // left unwritten by a failed section
+        const U32x2* scan = ps->scan[q] + (size_t)c * nq;
+        const int shift = ps->pass_shift;
+        const bool accumulate = im.num_passes > 1;
+        for (uint32_t i = lane; i < blk.y; i += 64) {
+          const uint32_t ent = entries[blk.x + i], k = ent & 0xFFFFu;
+          if (k >= nq) continue;
+          const uint32_t p = scan[k].x;
+          const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
+          const uint32_t ky = transposed ? cc : r, kx = transposed ? r : cc;
+          if (ky < (8u << lcy) && kx < (8u << lcx)) {
+            const int32_t v = ((int32_t)ent >> 16) * (1 << shift);
+            if (accumulate) atomicAdd(&plane[(size_t)ky * im.wp + kx], v);   // lanes of different passes may meet at one position
+            else plane[(size_t)ky * im.wp + kx] = v;
+          }
+        }
       }
     }
   }

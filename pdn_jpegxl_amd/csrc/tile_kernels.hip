@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     if (tid == 63) { ctot[0] = s_own; ctot[1] = s_y; }
   }
   for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
+  if (im.num_passes > 1) bad = 1;   // progressive frames: the passes' entries are summed as integers first (expand kernels, generic path)
   if (__syncthreads_or(bad)) {
     if (tid == 0 && cidx == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
     return;

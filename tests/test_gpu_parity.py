@@ -246,3 +246,26 @@ def test_corrupt_prefix_and_lz77_streams_fail_cleanly(gpu_decoder, oracle):
         except (api.FormatError, AssertionError):
             bad += 1
     assert bad >= 6   # most corruptions are detected (final states, ranges); none may crash or hang
+
+
+@pytest.mark.parametrize("passes", [2, 3])
+@pytest.mark.parametrize("extra", [dict(), dict(strategy_mode=2, seed=5), dict(prefix_codes=True, lz77=True)], ids=["plain", "varblocks", "prefix+lz77"])
+def test_progressive_passes(gpu_decoder, oracle, passes, extra):
+    """Progressive frames: the quantised coefficients arrive in 2 / 3 passes (own code and coefficient orders each, shifted shares);
+    the sum of the passes is what a one-pass frame carries, so the pixels equal the one-pass decode and every stage tap the oracle's."""
+    img = synth(700, 530, 75 + passes)
+    data, od = run_case(gpu_decoder, oracle, img, num_passes=passes, **extra)
+    one = oracle.decode(oracle.encode(img, **extra)).pixels
+    assert (od.pixels == one).all()
+    check_pixels(gpu_decode(gpu_decoder, [data])[0], one)
+
+
+def test_progressive_single_group_and_batch(gpu_decoder, oracle):
+    """A progressive frame that fits one group still has a table of contents (one section per pass); progressive and plain frames
+    share a batch."""
+    small = synth(200, 120, 81)
+    big = synth(600, 300, 82)
+    files = [oracle.encode(small, num_passes=2), oracle.encode(big), oracle.encode(big, num_passes=3), oracle.encode(small)]
+    outs = gpu_decode(gpu_decoder, files)
+    for f, o in zip(files, outs):
+        check_pixels(o, oracle.decode(f).pixels)

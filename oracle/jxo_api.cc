@@ -89,6 +89,7 @@ struct JxoEncodeParams {
 
 // Optional inputs of the NEXT jxo_encode call on this thread (kept out of the parameter struct so that its layout stays put):
 // an ICC profile to embed, and whether the 4 / 5 channels are CMYK[A].
+void jxo_last_encode_token_counts(uint64_t out[4]) { GetLastEncodeTokenCounts(out); }
 static thread_local std::vector<uint8_t> g_next_icc;
 static thread_local bool g_next_cmyk = false;
 static thread_local int g_next_frames = 1;

@@ -81,6 +81,9 @@ struct EncodeParams {
 };
 
 // rgba: interleaved RGBA8 (or RGB8 / Gray8 / GrayA8 according to nch), tight rows.
+// Token counts of the last VarDCT frame this thread encoded: LF coefficients, HF metadata, HF coefficients, alpha.
+void SetLastEncodeTokenCounts(const uint64_t n[4]);
+void GetLastEncodeTokenCounts(uint64_t n[4]);
 std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nch, const EncodeParams& p,
                                const uint8_t* exif = nullptr, size_t exif_size = 0, const uint8_t* xmp = nullptr,
                                size_t xmp_size = 0);

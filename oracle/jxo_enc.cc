@@ -536,6 +536,14 @@ struct VarDctEncoder {
     hg.Write(CeilLog2(ng), 0);              // num_hf_presets - 1
     hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);  // used_orders: none
     std::vector<EncCode> acode(np);
+    {   // token counts of the frame's four stream families (bench.py prices the GPU entropy stages per token with them)
+      uint64_t n[4] = {0, 0, 0, 0};
+      for (auto& t : lf_tok) n[0] += t.size();
+      for (auto& t : meta_tok) n[1] += t.size();
+      for (auto& t : ac_tok) n[2] += t.size();
+      for (auto& t : alpha_tok) n[3] += t.size();
+      SetLastEncodeTokenCounts(n);
+    }
     for (uint32_t pass = 0; pass < np; pass++) {
       if (pass) hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);   // every pass: its coefficient orders (none), then its code
       std::vector<const std::vector<Token>*> acsets;
@@ -658,6 +666,10 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
 }
 
 }  // namespace
+
+static thread_local uint64_t g_token_counts[4] = {0, 0, 0, 0};
+void SetLastEncodeTokenCounts(const uint64_t n[4]) { for (int i = 0; i < 4; i++) g_token_counts[i] = n[i]; }
+void GetLastEncodeTokenCounts(uint64_t n[4]) { for (int i = 0; i < 4; i++) n[i] = g_token_counts[i]; }
 
 std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nch, const EncodeParams& p, const uint8_t* exif,
                                size_t exif_size, const uint8_t* xmp, size_t xmp_size) {

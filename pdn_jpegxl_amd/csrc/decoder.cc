@@ -576,12 +576,20 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (auto& ep : f.extra_passes) b = std::max(b, hf_code_bytes(ep.acode));
     return b;
   };
-  const size_t kHfLdsTarget = 80 * 1024;
+  size_t kHfLdsTarget = 80 * 1024;
+  if (const char* e = getenv("JXLHIP_HF_LDS_KB")) kHfLdsTarget = (size_t)atoi(e) * 1024;   // experiment knob
   auto hf_per_wg = [&](const ParsedFrame& f) {
+    // the fewest workgroups whose (tables + lanes) fit the budget, the image's sections spread evenly over them: every workgroup
+    // carries a copy of the tables, so a small last workgroup (64 + 64 + 7 sections) costs a full LDS slot for a few lanes
     const int per_wave = 64 / lane_stride;
     const size_t tab = hf_table_bytes(f);
-    int lanes = tab + HfLaneLdsBytes(32) * per_wave <= kHfLdsTarget ? (int)((kHfLdsTarget - tab) / HfLaneLdsBytes(32)) / per_wave * per_wave : per_wave;
-    return std::max(per_wave, std::min(per_wg, lanes));
+    const int ng = std::max(1, (int)f.ng);
+    for (int nwg = 1; nwg <= ng; nwg++) {
+      const int lanes = (((ng + nwg - 1) / nwg) + per_wave - 1) / per_wave * per_wave;
+      if (lanes <= per_wg && tab + HfLaneLdsBytes(32) * (size_t)lanes <= kHfLdsTarget) return lanes;
+      if (lanes <= per_wave) break;
+    }
+    return per_wave;
   };
   int n_pass_wg = 0;
   for (int i = 0; i < n; i++)
@@ -611,6 +619,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // per wavefront, more only when a batch brings tens of thousands of LF groups.
   int lf_per_wave = 4;
   while (lf_per_wave < 64 && total_lf / lf_per_wave > 4096) lf_per_wave *= 2;
+  if (const char* e = getenv("JXLHIP_LF_PER_WAVE")) lf_per_wave = std::max(1, atoi(e));   // experiment knob
   int n_lf_ans = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_lf_ans += ((int)frames[i].nlf + lf_per_wave - 1) / lf_per_wave;
@@ -892,8 +901,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-    lds_lf = std::max(lds_lf, 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
-    lds_alpha = lds_lf;
+    lds_lf = std::max(lds_lf, (size_t)lf_per_wave * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    lds_alpha = std::max(lds_alpha, (size_t)per_alpha_wg * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     max_groups = std::max<int>(max_groups, (int)f.ng);
     // LF groups that intersect the decoded group rows (8 group rows per LF group row); HF groups of the decoded rows; alpha of the band
     const uint32_t lfy0 = (uint32_t)d.dec_gy0 / 8, lfy1 = ((uint32_t)d.dec_gy1 + 7) / 8;
@@ -958,6 +967,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
         alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, ag1 - g), 0};
   }
+  if (getenv("JXLHIP_DEBUG_LDS")) {
+    for (int i = 0; i < std::min(n, 8); i++)
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0)
+        fprintf(stderr, "[jxlhip] image %d: hf tables %zu B (clusters %u, log_alpha %u, contexts %zu), lanes/wg %d; modular tables: clusters %u log_alpha %u contexts %zu tree %zu\n", i,
+                hf_table_bytes(frames[i]), frames[i].acode.num_hist, frames[i].acode.log_alpha, frames[i].acode.ctx_map.size(), hf_per_wg(frames[i]),
+                frames[i].mcode.num_hist, frames[i].mcode.log_alpha, frames[i].mcode.ctx_map.size(), frames[i].tree.size());
+    fprintf(stderr, "[jxlhip] launch LDS: hf %zu B (lanes %zu), lf %zu B, alpha %zu B; hf workgroups %d x %d threads, stride %d; alpha workgroups %d; lf_ans workgroups %d\n",
+            lds_hf, lds_hf_lanes, lds_lf, lds_alpha, npass_t, hf_waves * 64, lane_stride, nalpha_t, nlf_ans_t);
+  }
   const int hf_ring = 32;   // words of the per-lane bit window
   const size_t kLdsMax = 150 * 1024;
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * imgs.size());
@@ -966,14 +984,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   stage_names.clear();
   S.stage_chain.clear();
   Mark("start", s_lf, 0);
-  HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
+  // experiment knob (timing only, the output is stale): bit 0 skips the LF chain, 1 the HF decode, 2 alpha, 3 reconstruction, 4 filters -
+  // with the same files resubmitted, a skipped stage's results of the previous batch in this workspace slot are still in place
+  static const int skip_stages = getenv("JXLHIP_SKIP_STAGES") ? atoi(getenv("JXLHIP_SKIP_STAGES")) : 0;
+  if (!(skip_stages & 1)) HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
-  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
+  if (!(skip_stages & 1)) {
+  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
   Mark("lf_ans", s_lf, 0);
   LaunchLfFinish(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, s_lf);
   LaunchHfBlockList(d_imgs, n, max_groups, s_lf);
   LaunchLfPixelStages(d_imgs, n, max_cells, s_lf);
+  }
   Mark("lf_finish+pixels", s_lf, 0);
   // three chains, three streams: LF (batch k+2) | HF coefficients (batch k+1) | alpha + pixels (batch k)
   if (s_lf != s_hf) {
@@ -981,11 +1004,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
   Mark("hf_start", s_hf, 1);
+  if (!(skip_stages & 2))
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, lds_hf_lanes, s_hf);
   Mark("hf_decode", s_hf, 1);
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages
-  if (any_alpha)
+  if (any_alpha && !(skip_stages & 4))
     LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, s_hf);
   Mark("alpha_ans", s_hf, 1);
   if (debug_taps) {   // the quantised coefficients as dense planes (every frame has its own planes in this mode)
@@ -994,7 +1018,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamSynchronize(stream));
     CopyPlaneTap(0);
   }
-  if (any_alpha) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
+  if (any_alpha && !(skip_stages & 4)) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
   Mark("alpha_finish", s_hf, 1);
   if (s_hf != stream) {
     HIP_OK(hipEventRecord(S.hf_done, s_hf));
@@ -1003,12 +1027,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   Mark("main_start", stream, 2);
   for (int c0 = 0; c0 < n; c0 += pixel_chunk) {
     const int cnt = std::min(pixel_chunk, n - c0);
+    if (!(skip_stages & 8))
     LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
     Mark("reconstruct", stream, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
     LaunchExpandCoefficients(d_imgs + c0, cnt, false, max_tiles, stream);
     LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, stream);
     Mark("reconstruct_generic", stream, 2);
     if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
+    if (!(skip_stages & 16))
     LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, stream);
     Mark("filters+output", stream, 2);
   }
@@ -1113,7 +1139,7 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
   uint64_t lf_end = 0;
   if (e == hipSuccess) {
     const size_t lds = 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + 8 + 8 * f.mcode.alias.size() + 4 * f.mcode.cfg.size() + f.mcode.ctx_map.size();
-    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, lds <= 150 * 1024 ? lds : 0, own_stream);
+    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, 64, lds <= 150 * 1024 ? lds : 0, own_stream);
     e = hipStreamSynchronize(own_stream);
   }
   if (e == hipSuccess) e = hipMemcpy(st_words, d + o_status, 64, hipMemcpyDeviceToHost);

@@ -109,7 +109,7 @@ struct LaneBitsT {
     while (filled + kBatch <= rd + kRing && filled - rd < (uint32_t)(kRing * 3 / 4)) Batch();
     if (filled + kBatch <= rd + kRing) { Fetch(pend); has_pend = true; }
   }
-  __device__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off, JXL_LDS uint32_t* ring_slot, uint32_t ring_stride) {
+  __device__ __forceinline__ void Init(const uint8_t* cs, uint64_t cs_size, uint64_t bit_off, JXL_LDS uint32_t* ring_slot, uint32_t ring_stride) {
     const uintptr_t addr = (uintptr_t)cs + (bit_off >> 3);
     const uintptr_t al = addr & ~(uintptr_t)31;
     w = (const JXL_GLB uint32_t*)al;
@@ -223,7 +223,7 @@ __device__ const int8_t d_special_dist[120][2] = {
     {8, 3}, {5, 7}, {-5, 7}, {7, 5}, {-7, 5}, {8, 4}, {6, 7}, {-6, 7}, {7, 6}, {-7, 6}, {8, 5}, {7, 7}, {-7, 7}, {8, 6}, {8, 7}};
 
 template <bool kLds, class Bits>
-__device__ __noinline__ uint32_t SlowSymbol(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t cl) {
+__device__ __forceinline__ uint32_t SlowSymbol(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t cl) {
   const DevCode& dc = *t.dc;
   if (dc.slow & 1) {
     const uint32_t c = t.cfg[cl];
@@ -258,7 +258,7 @@ __device__ __noinline__ uint32_t SlowSymbol(Bits& b, uint32_t& state, const Code
 }
 
 template <bool kLds, class Bits>
-__device__ __noinline__ uint32_t SlowGet(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
+__device__ __forceinline__ uint32_t SlowGet(Bits& b, uint32_t& state, const CodeTab<kLds>& t, uint32_t ctx) {
   const DevCode& dc = *t.dc;
   const bool lz = (dc.slow & 2) != 0 && b.lz_win != nullptr;
   if (lz && b.lz_copy) {
@@ -904,14 +904,16 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds>
-__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   ModTables<kLds> mt;
-  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  // `slots` lanes of the wavefront decode (the launch's sections per workgroup): the bit windows take slots * 128 B of LDS, not 8 KB -
+  // LDS is what decides whether this kernel can share a CU with the HF decoder of the batch before
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64);
   const int lane = threadIdx.x;
-  if (lane >= task.count) return;
+  if (lane >= task.count || lane >= slots) return;
   const int g = task.first + lane;
   const int gx = g % im.xlf, gy = g / im.xlf;
   const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
@@ -923,31 +925,32 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
   const int lf_sec = im.single ? 0 : 1 + g;
   const uint64_t start_bits = im.single ? im.lf_start_bits : im.sec_off[lf_sec] * 8;
   LaneBits b;
-  b.Init(im.cs, im.cs_size, im.alpha_in_global ? im.lf_start_bits : start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
+  b.Init(im.cs, im.cs_size, im.alpha_in_global ? im.lf_start_bits : start_bits, (JXL_LDS uint32_t*)smem + lane, (uint32_t)slots);
   uint32_t state = 0, err = 0, count = 1;
   int32_t* const wps = im.wp_lf ? im.wp_lf + (size_t)g * kWpLfInts : nullptr;
   uint32_t* const lzw = im.lz_lf ? im.lz_lf + ((size_t)g << 20) : nullptr;   // LZ77 window of this lane's streams
-  if (im.alpha_in_global) {
-    // the alpha channel of a frame that fits one group is coded in the GlobalModular part of LfGlobal (stream 0), which the LF group
-    // follows directly (one-section frames) or in a section of its own (progressive frames: one section per pass)
-    b.SetLz(lzw, 20, (uint32_t)im.w);
-    b.lz_copy = 0; b.lz_done = 0;
-    state = InitAnsState(b, mt.tab);
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, 0, im.w, im.h, im.alpha32, im.w, im.alpha_desc, wps);
-    if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
-    if (!im.single) {
-      if (im.lf_start_bits + b.Consumed() > (im.sec_off[0] + im.sec_size[0]) * 8) err |= kErrBitstream;
-      b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, 64);
-    }
-  }
-  if (!err) {
-    im.lf_extra[g] = (uint8_t)b.Read(2);
-    if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
-  }
-  // seven channels, one loop (a single inlined copy of the channel decoder): 0-2 LF coefficients, 3-6 HF metadata
+  // Eight channels, one loop (a single inlined copy of the channel decoder; a second call site makes it a real call, which puts the
+  // bit reader in scratch memory): -1 the alpha channel of a frame that fits one group - it is coded in the GlobalModular part of
+  // LfGlobal (stream 0), which the LF group follows directly (one-section frames) or in a section of its own (progressive frames:
+  // one section per pass); 0-2 LF coefficients; 3-6 HF metadata
 #pragma unroll 1
-  for (int i = 0; i < 7 && !err; i++) {
-    if (i == 0) {   // the LF stream: three channels bw wide
+  for (int i = im.alpha_in_global ? -1 : 0; i < 7 && !err; i++) {
+    if (i == -1) {
+      b.SetLz(lzw, 20, (uint32_t)im.w);
+      b.lz_copy = 0; b.lz_done = 0;
+      state = InitAnsState(b, mt.tab);
+    }
+    if (i == 0) {
+      if (im.alpha_in_global) {
+        if (state != 0x130000u || b.slow_err) { err |= kErrBitstream; break; }
+        if (!im.single) {
+          if (im.lf_start_bits + b.Consumed() > (im.sec_off[0] + im.sec_size[0]) * 8) { err |= kErrBitstream; break; }
+          b.Init(im.cs, im.cs_size, start_bits, (JXL_LDS uint32_t*)smem + lane, (uint32_t)slots);
+        }
+      }
+      im.lf_extra[g] = (uint8_t)b.Read(2);
+      if (b.Read(4) != 3) { err |= kErrUnsupportedHeader; break; }
+      // the LF stream: three channels bw wide
       b.SetLz(lzw, 20, (uint32_t)bw);
       b.lz_copy = 0; b.lz_done = 0;
       state = InitAnsState(b, mt.tab);
@@ -964,7 +967,10 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
     }
     int chan, sid, w, h, stride;
     int32_t* out;
-    if (i < 3) {
+    ChanDesc* cd = desc + max(i, 0);
+    if (i < 0) {
+      chan = 0; sid = 0; w = im.w; h = im.h; stride = im.w; out = im.alpha32; cd = im.alpha_desc;
+    } else if (i < 3) {
       const int c = i == 0 ? 1 : (i == 1 ? 0 : 2);   // modular channel order Y, X, B
       chan = i; sid = 1 + g; w = bw; h = bh; stride = im.w8;
       out = im.lfq[c] + (size_t)by0 * im.w8 + bx0;
@@ -974,7 +980,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
       else if (i == 5) { w = (int)count; h = 2; stride = (int)count; out = scratch + 2048; }
       else { w = bw; h = bh; stride = bw; out = scratch + 2048 + 2 * 65536; }
     }
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, desc + i, wps);
+    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, cd, wps);
   }
   if (!err && (state != 0x130000u || b.slow_err || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
   if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
@@ -1368,9 +1374,10 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
   const DevImage& im = imgs[task.image];
   if (!im.has_alpha || im.alpha_in_global) return;
   ModTables<kLds> mt;
-  LoadModTables<kLds>(im, smem, (size_t)64 * kRingWords * 4, mt, threadIdx.x, 64);
+  const int slots = 64 / lane_stride;
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64);
   const int lane = threadIdx.x;
-  if (lane >= 64 / lane_stride || lane >= task.count) return;
+  if (lane >= slots || lane >= task.count) return;
   const int g = task.first + lane;
   ChanDesc* desc = im.alpha_desc + g;
   const uint64_t start = im.alpha_bitpos[g];
@@ -1383,7 +1390,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
   const int gx = g % im.xg, gy = g / im.xg;
   const int sec = im.alpha_sec_base + g;
   LaneBits b;
-  b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, 64);
+  b.Init(im.cs, im.cs_size, start, (JXL_LDS uint32_t*)smem + lane, (uint32_t)slots);
   uint32_t err = 0;
   if (b.Read(4) != 3) err |= kErrUnsupportedHeader;
   else {
@@ -1689,13 +1696,13 @@ static void RaiseLds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s) {
-  if (ntasks <= 0) return;
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, hipStream_t s) {
+  if (ntasks <= 0) return;   // slots: sections per workgroup (lanes that decode); lds_bytes: their bit windows + the tables (0: tables stay global)
   if (lds_bytes) {
     RaiseLds((const void*)lf_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks);
+    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots);
   } else {
-    hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), 64 * kRingWords * 4, s, imgs, tasks);
+    hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), (size_t)slots * kRingWords * 4, s, imgs, tasks, slots);
   }
 }
 
@@ -1730,7 +1737,7 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
     RaiseLds((const void*)alpha_ans_kernel<true>, lds_bytes);
     hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride);
   } else {
-    hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), 64 * kRingWords * 4, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), (size_t)(64 / lane_stride) * kRingWords * 4, s, imgs, tasks, lane_stride);
   }
 }
 

@@ -7,7 +7,7 @@ namespace jxlhip {
 
 // entropy_kernels.hip (lds_bytes == 0 selects the variant that keeps its tables in global memory)
 // LF groups: phase A (ANS, one lane per LF group, one wavefront per image chunk) and phase B (one workgroup per LF group)
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, size_t lds_bytes, hipStream_t s);
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, hipStream_t s);
 void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);

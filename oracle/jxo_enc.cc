@@ -212,6 +212,11 @@ struct VarDctEncoder {
           int area = kCoveredX[cand] * kCoveredY[cand];
           if (area >= 256 && (rng.Next() % 4)) cand = kAll[rng.Next() % 14];
           s = fits(bx, by, cand) ? cand : DCT8;
+        } else if (p.strategy_mode == 4) {
+          // the square transforms only (what the product's encoder chooses between at its default effort)
+          static const struct { int s; float t; } kSquares[] = {{DCT32X32, 0.007f}, {DCT16X16, 0.016f}};
+          for (auto& t : kSquares)
+            if (fits(bx, by, t.s) && max_act(bx, by, kCoveredX[t.s], kCoveredY[t.s]) < t.t) { s = t.s; break; }
         } else {
           static const struct { int s; float t; } kTry[] = {{DCT64X64, 0.0035f}, {DCT64X32, 0.0045f}, {DCT32X64, 0.0045f},
                                                            {DCT32X32, 0.007f},  {DCT32X16, 0.009f},  {DCT16X32, 0.009f},

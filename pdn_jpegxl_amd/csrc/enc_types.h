@@ -15,7 +15,7 @@ enum EncLeaf : uint32_t {
 constexpr uint32_t kEncSyms = 128;            // token alphabet of the fixed hybrid-uint config (4, 2, 0)
 constexpr uint32_t kAcContexts = 495 * 15;    // one preset, default block-context map
 constexpr uint32_t kLfTokCap = 3 * 65536;     // tokens per LF group: LF coefficients
-constexpr uint32_t kMetaTokCap = 65536;       // ... and quant-field row of the block info
+constexpr uint32_t kMetaTokCap = 2 * 65536;   // ... and the two rows of the block info (strategies, quant field)
 constexpr uint32_t kAcTokCap = 3 * 65 * 1024; // tokens per group: 1 + 64 per (block, channel)
 constexpr uint32_t kAlphaTokCap = 65536;
 constexpr uint32_t kLlTokCap = 4 * 65536;     // lossless: up to four channels per group
@@ -45,9 +45,14 @@ struct EncImage {
   int32_t* alpha_px;        // w*h
   int32_t* lfq[3];          // w8*h8 quantised LF (X, Y, B)
   int32_t* rawq;            // w8*h8 raw quant field (1..256)
-  int32_t* qs[3];           // w8*h8*64 quantised coefficients in scan order
-  uint8_t* nz[3];           // per cell: number of non-zero HF coefficients
-  uint8_t* last[3];         // per cell: scan position of the last non-zero coefficient (0: none)
+  // varblocks: 8x8, 16x16 or 32x32 DCTs (the squares the block kernel chooses between; `squares` = 0: 8x8 only, the fast effort)
+  int32_t squares, pad1;
+  float* act;               // w8*h8 activity of Y per cell (standard deviation)
+  uint8_t* strat;           // w8*h8: strategy of the varblock covering the cell (0 DCT8, 4 DCT16X16, 5 DCT32X32) | 0x80 on its first cell
+  int32_t* qs[3];           // w8*h8*64 quantised coefficients: scan position k of a varblock at its covered cell (k >> 6, row-major) * 64 + (k & 63)
+  uint8_t* nz[3];           // per cell: the non-zero context value of the varblock covering it, (count + covered - 1) >> log2(covered)
+  uint16_t* nzc[3];         // per first cell: number of non-zero HF coefficients of the varblock
+  uint16_t* last[3];        // per first cell: scan position of the last non-zero coefficient (0: none)
   // quantiser
   float inv_mul_lf[3];      // 1 / (m_lf * inv_global_scale / quant_lf)
   float mul_lf_y;           // LF dequant step of Y (chroma-from-luma of the LF uses the dequantised Y)
@@ -55,15 +60,21 @@ struct EncImage {
   float x_dm, b_dm;         // 0.8 ^ (x_qm_scale - 2), 0.8 ^ (b_qm_scale - 2)
   float qbias1, qbias3;     // quantisation bias of |q| == 1 (Y) and the 1/q term
   float gab_w[3][3];
-  const uint16_t* order8;   // natural order of the 8x8 DCT (scan position -> stored index kx * 8 + ky)
-  const float* dq8;         // 3 * 64 dequantisation multipliers (stored layout)
-  const float* basis8;      // B[k * 8 + n]
+  // per transform size N = 8, 16, 32 (index 0..2): inverse natural order (stored index kx * N + ky -> scan position), 3 * N * N
+  // dequantisation multipliers (stored layout), the basis B[k * N + n] and the same divided by N
+  const uint16_t* scan_of[3];
+  const float* dq[3];
+  const float* basis[3];
+  const float* basis_div[3];
+  const float* bsmall[3];   // c x c basis for c = 1, 2, 4 (LF values of a varblock from its lowest c x c coefficients)
+  float rs[3][16];          // resample scale of coefficient (ky, kx) of the lowest c x c, [ky * c + kx], c = 1, 2, 4
   // tokens
   DevToken* tok_lf;         // [nlf][kLfTokCap]
   DevToken* tok_meta;       // [nlf][kMetaTokCap]
   DevToken* tok_ac;         // [ng][kAcTokCap]
   DevToken* tok_alpha;      // [ng][kAlphaTokCap]
   uint32_t* n_ac;           // [ng]
+  uint32_t* n_meta;         // [nlf] tokens of the block-info stream
   uint32_t* hist_mod;       // [kNumEncLeaves][kEncSyms]
   uint32_t* hist_ac;        // [kAcContexts][kEncSyms]
   // lossless (Modular) frames: whole-image integer channels, tokens per group

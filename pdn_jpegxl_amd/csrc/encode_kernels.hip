@@ -4,8 +4,10 @@
 //   enc_analyze_kernel        GetOutputPixelFormat (:33-77): is every pixel gray / opaque?                 (reduction)
 //   enc_xyb_kernel            PixelFormatConversion (BGRA -> channels) + sRGB -> linear -> XYB              (elementwise)
 //   enc_sharpen_pad_kernel    inverse-Gaborish pre-sharpening, edge replication to whole 8x8 cells          (3x3 stencil)
-//   enc_block_kernel          one wavefront per 8x8 block: DCT, adaptive quant field, LF + HF quantisation
-//                             with chroma from luma, coefficients in scan order, non-zero statistics
+//   enc_activity / enc_strategy / enc_varblock_kernel
+//                             per-cell activity; 8x8 / 16x16 / 32x32 DCT per aligned region from it (effort), adaptive quant
+//                             field; one workgroup per 32x32 region: DCTs, LF + HF quantisation with chroma from luma,
+//                             coefficients in scan order, non-zero statistics
 //   enc_*_tokens_kernel       context modelling: (context, value) tokens + histograms, all data-parallel
 //   enc_sections_kernel       ANS coding, one lane per section (reverse pass for the state, forward pass for the bits)
 #include <hip/hip_runtime.h>
@@ -111,77 +113,201 @@ __global__ void enc_sharpen_pad_kernel(EncImage im) {
   }
 }
 
-// ------------------------------------------------------------------ one wavefront per 8x8 block
-// lane = scan position.  Forward DCT as two 8-point passes through LDS, activity -> raw quant, LF and HF quantisation.
-__global__ __launch_bounds__(256) void enc_block_kernel(EncImage im) {
-  __shared__ float s_px[4][3][64];
-  __shared__ float s_t[4][3][64];
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int cell = blockIdx.x * 4 + wv;
+// ------------------------------------------------------------------ varblocks: strategy choice, DCT, quantisation
+// Activity of a cell: standard deviation of its 64 Y samples (double accumulation: the strategy thresholds below compare it).
+__global__ void enc_activity_kernel(EncImage im) {
   const int ncell = im.w8 * im.h8;
-  const bool live = cell < ncell;
-  const int bx = live ? cell % im.w8 : 0, by = live ? cell / im.w8 : 0;
-  const int py = lane >> 3, pxx = lane & 7;
-  float pix[3];
-  for (int c = 0; c < 3; c++) {
-    pix[c] = im.pad[c][(size_t)(by * 8 + py) * im.wp + bx * 8 + pxx];
-    s_px[wv][c][lane] = pix[c];
+  for (int cell = blockIdx.x * blockDim.x + threadIdx.x; cell < ncell; cell += gridDim.x * blockDim.x) {
+    const int bx = cell % im.w8, by = cell / im.w8;
+    const float* p = im.pad[1] + (size_t)by * 8 * im.wp + bx * 8;
+    double s = 0, s2 = 0;
+    for (int y = 0; y < 8; y++)
+      for (int x = 0; x < 8; x++) {
+        const float v = p[(size_t)y * im.wp + x];
+        s += v; s2 += (double)v * v;
+      }
+    const double var = s2 / 64 - (s / 64) * (s / 64);
+    im.act[cell] = (float)sqrt(var > 0 ? var : 0.0);
+  }
+}
+
+// One thread per aligned 32x32 region (4 x 4 cells): a 32x32 DCT if the region is inside the frame and flat, else per aligned 16x16
+// quadrant a 16x16 DCT under the same test with its own threshold, else 8x8 DCTs - the raster-greedy choice over aligned squares.
+// The quant field of a varblock follows its mean activity (finer steps in flat areas).
+__global__ void enc_strategy_kernel(EncImage im) {
+  const int rw = (im.w8 + 3) / 4, rh = (im.h8 + 3) / 4;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rw * rh; r += gridDim.x * blockDim.x) {
+    const int bx0 = (r % rw) * 4, by0 = (r / rw) * 4;
+    auto act = [&](int ix, int iy) { return im.act[(size_t)(by0 + iy) * im.w8 + bx0 + ix]; };
+    auto place = [&](int ix, int iy, int c, int strategy) {   // c x c cells from (ix, iy)
+      double a = 0;
+      for (int y = 0; y < c; y++) for (int x = 0; x < c; x++) a += act(ix + x, iy + y);
+      a /= c * c;
+      const double mod = 0.7 + 0.8 / (1.0 + a / 0.012);
+      int q = (int)rint(16.0 * mod);
+      q = max(1, min(256, q));
+      for (int y = 0; y < c; y++)
+        for (int x = 0; x < c; x++) {
+          const size_t cell = (size_t)(by0 + iy + y) * im.w8 + bx0 + ix + x;
+          im.strat[cell] = (uint8_t)(strategy | ((x | y) == 0 ? 0x80 : 0));
+          im.rawq[cell] = q;
+        }
+    };
+    const bool whole = im.squares && bx0 + 4 <= im.w8 && by0 + 4 <= im.h8;
+    float mx = 0.f;
+    if (whole) for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) mx = fmaxf(mx, act(x, y));
+    if (whole && mx < 0.007f) { place(0, 0, 4, 5); continue; }
+    for (int qy = 0; qy < 4; qy += 2)
+      for (int qx = 0; qx < 4; qx += 2) {
+        const bool inside = bx0 + qx + 2 <= im.w8 && by0 + qy + 2 <= im.h8;
+        if (im.squares && inside && fmaxf(fmaxf(act(qx, qy), act(qx + 1, qy)), fmaxf(act(qx, qy + 1), act(qx + 1, qy + 1))) < 0.016f) { place(qx, qy, 2, 4); continue; }
+        for (int y = 0; y < 2; y++)
+          for (int x = 0; x < 2; x++)
+            if (bx0 + qx + x < im.w8 && by0 + qy + y < im.h8) place(qx + x, qy + y, 1, 0);
+      }
+  }
+}
+
+// One workgroup per 32x32 region: every sample position of the region belongs to exactly one varblock, so both DCT passes run over
+// all 1024 positions at once (a thread's loop length is its varblock's side), through LDS.  Then per coefficient: its scan position,
+// quantisation (Y first; X; B after chroma from luma with the dequantised Y), non-zero statistics; and per cell the quantised LF
+// from the varblock's lowest c x c coefficients.
+__global__ __launch_bounds__(256) void enc_varblock_kernel(EncImage im) {
+  constexpr int P = 33;
+  __shared__ float s_a[3][32 * P];   // pixels, later the coefficients
+  __shared__ float s_t[3][32 * P];   // after the vertical pass
+  __shared__ uint8_t s_strat[16];
+  __shared__ uint32_t s_nz[16][3], s_last[16][3];
+  const int rw = (im.w8 + 3) / 4;
+  const int bx0 = (blockIdx.x % rw) * 4, by0 = (blockIdx.x / rw) * 4;
+  const int tid = threadIdx.x;
+  if (tid < 16) {
+    const int ix = tid & 3, iy = tid >> 2;
+    s_strat[tid] = (bx0 + ix < im.w8 && by0 + iy < im.h8) ? im.strat[(size_t)(by0 + iy) * im.w8 + bx0 + ix] : 0xFF;   // 0xFF: outside the frame
+    for (int c = 0; c < 3; c++) { s_nz[tid][c] = 0; s_last[tid][c] = 0; }
+  }
+  for (int i = tid; i < 1024; i += 256) {
+    const int y = i >> 5, x = i & 31;
+    const bool in = bx0 * 8 + x < im.wp && by0 * 8 + y < im.hp;
+    for (int c = 0; c < 3; c++) s_a[c][y * P + x] = in ? im.pad[c][(size_t)(by0 * 8 + y) * im.wp + bx0 * 8 + x] : 0.f;
   }
   __syncthreads();
-  // vertical pass: t[ky][x] = 1/8 sum_y px[y][x] B[ky][y]   (this lane: ky = py, x = pxx)
-  for (int c = 0; c < 3; c++) {
-    float a = 0.f;
-    for (int y = 0; y < 8; y++) a += s_px[wv][c][y * 8 + pxx] * im.basis8[py * 8 + y];
-    s_t[wv][c][lane] = a * 0.125f;
+  // geometry of the varblock that holds region position (y, x): side N (8 << lc), origin (oy, ox), all from the cell's strategy
+  auto geom = [&](int y, int x, int* lc, int* oy, int* ox) -> bool {
+    const uint32_t st = s_strat[(y >> 3) * 4 + (x >> 3)];
+    if (st == 0xFF) return false;
+    const int l = (st & 0x7F) == 5 ? 2 : ((st & 0x7F) == 4 ? 1 : 0);
+    *lc = l;
+    *oy = y & ~((8 << l) - 1);
+    *ox = x & ~((8 << l) - 1);
+    return true;
+  };
+  // vertical: t[oy + ky][x] = sum_y px[oy + y][x] * (B[ky][y] / N)
+  for (int i = tid; i < 1024; i += 256) {
+    const int y = i >> 5, x = i & 31;
+    int lc, oy, ox;
+    if (!geom(y, x, &lc, &oy, &ox)) continue;
+    const int N = 8 << lc, ky = y - oy;
+    const float* b = im.basis_div[lc] + ky * N;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < N; k++) {
+      const float bv = b[k];
+      for (int c = 0; c < 3; c++) acc[c] += bv * s_a[c][(oy + k) * P + x];
+    }
+    for (int c = 0; c < 3; c++) s_t[c][y * P + x] = acc[c];
   }
   __syncthreads();
-  const uint32_t p = im.order8[lane];          // stored index kx * 8 + ky
-  const int kx = p >> 3, ky = p & 7;
-  float coef[3];
-  for (int c = 0; c < 3; c++) {
-    float a = 0.f;
-    for (int x = 0; x < 8; x++) a += s_t[wv][c][ky * 8 + x] * im.basis8[kx * 8 + x];
-    coef[c] = a * 0.125f;
+  // horizontal: coef[ky][kx] = (sum_x t[ky][ox + x] * B[kx][x]) / N ; kept in registers until every thread has read its inputs
+  float coef[4][3];
+  for (int j = 0; j < 4; j++) {
+    const int i = tid + j * 256, y = i >> 5, x = i & 31;
+    int lc, oy, ox;
+    coef[j][0] = coef[j][1] = coef[j][2] = 0.f;
+    if (!geom(y, x, &lc, &oy, &ox)) continue;
+    const int N = 8 << lc, kx = x - ox;
+    const float* b = im.basis[lc] + kx * N;
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int k = 0; k < N; k++) {
+      const float bv = b[k];
+      for (int c = 0; c < 3; c++) acc[c] += s_t[c][y * P + ox + k] * bv;
+    }
+    for (int c = 0; c < 3; c++) coef[j][c] = acc[c] / (float)N;
   }
-  // activity of Y -> raw quant (finer steps in flat areas)
-  float s = pix[1], s2 = pix[1] * pix[1];
-  for (int o = 32; o; o >>= 1) { s += __shfl_xor(s, o); s2 += __shfl_xor(s2, o); }
-  const float mean = s * (1.0f / 64), var = fmaxf(0.f, s2 * (1.0f / 64) - mean * mean);
-  const float act = sqrtf(var);
-  const float mod = 0.7f + 0.8f / (1.0f + act / 0.012f);
-  int q = (int)rintf(16.0f * mod);
-  q = max(1, min(256, q));
-  if (!live) return;
-  if (lane == 0) {
-    im.rawq[cell] = q;
-    // LF: Y first; X and B code the residual after the LF chroma-from-luma (base correlation 0 for X, 1 for B)
-    const int32_t qy = (int32_t)rintf(coef[1] * im.inv_mul_lf[1]);
-    const float fy = (float)qy * im.mul_lf_y;
-    im.lfq[1][cell] = qy;
-    im.lfq[0][cell] = (int32_t)rintf(coef[0] * im.inv_mul_lf[0]);
-    im.lfq[2][cell] = (int32_t)rintf((coef[2] - fy) * im.inv_mul_lf[2]);
+  __syncthreads();
+  for (int j = 0; j < 4; j++) {
+    const int i = tid + j * 256, y = i >> 5, x = i & 31;
+    for (int c = 0; c < 3; c++) s_a[c][y * P + x] = coef[j][c];
   }
-  const float scale = im.inv_gs / (float)q;
-  const float dqs[3] = {scale * im.x_dm, scale, scale * im.b_dm};
-  int32_t qi[3] = {0, 0, 0};
-  float yd = 0.f;
-  if (lane >= 1) {
-    const float wy = im.dq8[64 + p];
-    const float vy = coef[1] / (dqs[1] * wy);
-    qi[1] = fabsf(vy) < 0.6f ? 0 : (int32_t)rintf(vy);
-    const float adj = qi[1] == 0 ? 0.f : (abs(qi[1]) == 1 ? (qi[1] > 0 ? im.qbias1 : -im.qbias1) : (float)qi[1] - im.qbias3 / (float)qi[1]);
-    yd = adj * dqs[1] * wy;
-    const float vx = coef[0] / (dqs[0] * im.dq8[p]);
-    qi[0] = fabsf(vx) < 0.6f ? 0 : (int32_t)rintf(vx);
-    const float vb = (coef[2] - yd) / (dqs[2] * im.dq8[128 + p]);
-    qi[2] = fabsf(vb) < 0.6f ? 0 : (int32_t)rintf(vb);
+  __syncthreads();
+  // quantisation of the HF coefficients
+  for (int j = 0; j < 4; j++) {
+    const int i = tid + j * 256, y = i >> 5, x = i & 31;
+    int lc, oy, ox;
+    if (!geom(y, x, &lc, &oy, &ox)) continue;
+    const int N = 8 << lc, ky = y - oy, kx = x - ox, cc = 1 << lc;
+    const uint32_t p = (uint32_t)(kx * N + ky);          // stored (transposed) layout of a square DCT
+    const uint32_t k = im.scan_of[lc][p];
+    const int fcell = (oy >> 3) * 4 + (ox >> 3);         // first cell of the varblock, within the region
+    const size_t first = (size_t)(by0 + (oy >> 3)) * im.w8 + bx0 + (ox >> 3);
+    const float scale = im.inv_gs / (float)im.rawq[first];
+    const float dqs[3] = {scale * im.x_dm, scale, scale * im.b_dm};
+    int32_t qi[3] = {0, 0, 0};
+    if (!(ky < cc && kx < cc)) {   // the lowest c x c coefficients travel with the LF image
+      const float* dq = im.dq[lc];
+      const float wy = dq[N * N + p];
+      const float vy = coef[j][1] / (dqs[1] * wy);
+      qi[1] = fabsf(vy) < 0.6f ? 0 : (int32_t)rintf(vy);
+      const float adj = qi[1] == 0 ? 0.f : (abs(qi[1]) == 1 ? (qi[1] > 0 ? im.qbias1 : -im.qbias1) : (float)qi[1] - im.qbias3 / (float)qi[1]);
+      const float yd = adj * dqs[1] * wy;
+      const float vx = coef[j][0] / (dqs[0] * dq[p]);
+      qi[0] = fabsf(vx) < 0.6f ? 0 : (int32_t)rintf(vx);
+      const float vb = (coef[j][2] - yd) / (dqs[2] * dq[2 * N * N + p]);
+      qi[2] = fabsf(vb) < 0.6f ? 0 : (int32_t)rintf(vb);
+    }
+    // scan position k lives in the slot of the varblock's covered cell number k >> 6 (row-major)
+    const uint32_t cj = k >> 6;
+    const size_t slot = (first + (size_t)(cj >> lc) * im.w8 + (cj & (cc - 1))) * 64 + (k & 63);
+    for (int c = 0; c < 3; c++) {
+      im.qs[c][slot] = qi[c];
+      if (qi[c]) { atomicAdd(&s_nz[fcell][c], 1u); atomicMax(&s_last[fcell][c], k); }
+    }
   }
-  for (int c = 0; c < 3; c++) {
-    im.qs[c][(size_t)cell * 64 + lane] = qi[c];
-    const uint64_t m = __ballot(qi[c] != 0);
-    if (lane == 0) {
-      im.nz[c][cell] = (uint8_t)__popcll(m);
-      im.last[c][cell] = m ? (uint8_t)(63 - __clzll((long long)m)) : 0;
+  __syncthreads();
+  // per cell: non-zero context value of its varblock, LF from the lowest c x c coefficients; per first cell: counts
+  if (tid < 16) {
+    const int ix = tid & 3, iy = tid >> 2;
+    const uint32_t st = s_strat[tid];
+    if (st != 0xFF) {
+      int lc, oy, ox;
+      geom(iy * 8, ix * 8, &lc, &oy, &ox);
+      const int cc = 1 << lc, fcell = (oy >> 3) * 4 + (ox >> 3), cy = iy - (oy >> 3), cx = ix - (ox >> 3);
+      const size_t cell = (size_t)(by0 + iy) * im.w8 + bx0 + ix;
+      float lf[3];
+      for (int c = 0; c < 3; c++) {
+        // IDCT of the c x c lowest coefficients, undoing the resampling scale
+        const float* B = im.bsmall[lc];
+        float out = 0.f;
+        // horizontal then vertical, as the reference order of summation (tmp[ky][x] over kx, then over ky)
+        for (int ky = 0; ky < cc; ky++) {
+          float t = 0.f;
+          for (int kx = 0; kx < cc; kx++) {
+            const float v = s_a[c][(oy + ky) * P + ox + kx] / im.rs[lc][ky * cc + kx];
+            t += v * B[kx * cc + cx];
+          }
+          out += B[ky * cc + cy] * t;
+        }
+        lf[c] = out;
+      }
+      const int32_t qy = (int32_t)rintf(lf[1] * im.inv_mul_lf[1]);
+      const float fy = (float)qy * im.mul_lf_y;
+      im.lfq[1][cell] = qy;
+      im.lfq[0][cell] = (int32_t)rintf(lf[0] * im.inv_mul_lf[0]);
+      im.lfq[2][cell] = (int32_t)rintf((lf[2] - fy) * im.inv_mul_lf[2]);
+      for (int c = 0; c < 3; c++) {
+        const uint32_t n = s_nz[fcell][c];
+        im.nz[c][cell] = (uint8_t)((n + (uint32_t)(cc * cc) - 1) >> (2 * lc));
+        if (st & 0x80) { im.nzc[c][cell] = (uint16_t)n; im.last[c][cell] = (uint16_t)s_last[fcell][c]; }
+      }
     }
   }
 }
@@ -225,32 +351,73 @@ __global__ __launch_bounds__(256) void enc_lf_tokens_kernel(EncImage im) {
   }
 }
 
-// quant-field row of the block info (every cell is one 8x8 block): West predictor
-__global__ __launch_bounds__(256) void enc_meta_tokens_kernel(EncImage im) {
-  __shared__ uint32_t s_h[kEncSyms];
-  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256) s_h[i] = 0;
-  __syncthreads();
-  const int g = blockIdx.y;
+// Block info of an LF group: its varblocks in raster order of their first cells, row 0 = strategies (Zero predictor), row 1 = quant
+// field - 1 (West predictor; the first entry's West is the sample above it, i.e. the first strategy).  One workgroup per LF group:
+// first cells per 64-cell run (one ballot each), a scan over the runs, then both rows are written in parallel.
+__global__ __launch_bounds__(1024) void enc_meta_tokens_kernel(EncImage im) {
+  __shared__ uint32_t s_hq[kEncSyms], s_hs[kEncSyms];
+  __shared__ uint32_t s_run[1024 + 1];   // first cells before run r (65536 cells / 64)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < (int)kEncSyms; i += 1024) { s_hq[i] = 0; s_hs[i] = 0; }
+  const int g = blockIdx.x;
   const int gx = g % im.xlf, gy = g / im.xlf;
   const int bx0 = gx * kLfGroupBlocks, by0 = gy * kLfGroupBlocks;
   const int bw = min(kLfGroupBlocks, im.w8 - bx0), bh = min(kLfGroupBlocks, im.h8 - by0);
-  const int n = bw * bh;
-  DevToken* out = im.tok_meta + (size_t)g * kMetaTokCap;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    auto at = [&](int k) { return im.rawq[(size_t)(by0 + k / bw) * im.w8 + bx0 + k % bw] - 1; };
-    // row 1 of a (count x 2) channel: West is the previous entry; for the first entry it is the sample above = strategy 0
-    const int32_t v = at(i), W = i ? at(i - 1) : 0;
-    DevToken t;
-    t.ctx = kLeafQf;
-    t.value = PackSignedD(v - W);
-    out[i] = t;
-    uint32_t tok, nb, bits;
-    HybridD(t.value, &tok, &nb, &bits);
-    atomicAdd(&s_h[tok], 1u);
+  const int n = bw * bh, nrun = (n + 63) / 64;
+  auto cell_of = [&](int k) { return (size_t)(by0 + k / bw) * im.w8 + bx0 + k % bw; };
+  for (int r = wave; r < nrun; r += 16) {
+    const int k = r * 64 + lane;
+    const uint64_t m = __ballot(k < n && (im.strat[cell_of(k)] & 0x80));
+    if (lane == 0) s_run[r + 1] = (uint32_t)__popcll(m);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < (int)kEncSyms; i += 256)
-    if (s_h[i]) atomicAdd(&im.hist_mod[kLeafQf * kEncSyms + i], s_h[i]);
+  if (tid == 0) {
+    uint32_t acc = 0;
+    s_run[0] = 0;
+    for (int i = 1; i <= nrun; i++) { acc += s_run[i]; s_run[i] = acc; }
+  }
+  __syncthreads();
+  const uint32_t count = s_run[nrun];
+  DevToken* out = im.tok_meta + (size_t)g * kMetaTokCap;
+  const bool with_strategies = im.squares != 0;   // 8x8 only: the strategy row is a constant channel, no token is written for it
+  const uint32_t qbase = with_strategies ? count : 0;
+  for (int r = wave; r < nrun; r += 16) {
+    const int k = r * 64 + lane;
+    const bool first = k < n && (im.strat[cell_of(k)] & 0x80);
+    const uint64_t m = __ballot(first);
+    if (!first) continue;
+    const uint32_t idx = s_run[r] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    const size_t cell = cell_of(k);
+    const int32_t strategy = im.strat[cell] & 0x7F;
+    uint32_t tok, nb, bits;
+    DevToken t;
+    if (with_strategies) {
+      t.ctx = kLeafStrategy;
+      t.value = PackSignedD(strategy);
+      out[idx] = t;
+      HybridD(t.value, &tok, &nb, &bits);
+      atomicAdd(&s_hs[tok], 1u);
+    }
+    // West of the quant row: the previous varblock's value (walk back to the previous first cell); for the first varblock the
+    // sample above, which is its strategy
+    int32_t W = strategy;
+    if (idx) {
+      int kk = k - 1;
+      while (!(im.strat[cell_of(kk)] & 0x80)) kk--;
+      W = im.rawq[cell_of(kk)] - 1;
+    }
+    t.ctx = kLeafQf;
+    t.value = PackSignedD(im.rawq[cell] - 1 - W);
+    out[qbase + idx] = t;
+    HybridD(t.value, &tok, &nb, &bits);
+    atomicAdd(&s_hq[tok], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) im.n_meta[g] = qbase + count;
+  for (int i = tid; i < (int)kEncSyms; i += 1024) {
+    if (s_hq[i]) atomicAdd(&im.hist_mod[kLeafQf * kEncSyms + i], s_hq[i]);
+    if (s_hs[i]) atomicAdd(&im.hist_mod[kLeafStrategy * kEncSyms + i], s_hs[i]);
+  }
 }
 
 // alpha: one lossless Modular channel per group, gradient predictor
@@ -290,8 +457,8 @@ __global__ __launch_bounds__(256) void enc_alpha_tokens_kernel(EncImage im) {
 }
 
 // ------------------------------------------------------------------ tokens: HF coefficients of one group
-// Token counts per (block, channel) are known from the block kernel, so an exclusive scan gives every (block, channel)
-// its slot and all of them are tokenised in parallel.
+// Token counts per (varblock, channel) are known from the block kernel, so an exclusive scan over the group's cells (zero for
+// cells that are not the first of a varblock) gives every (varblock, channel) its slot and all of them are tokenised in parallel.
 __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
   __shared__ uint32_t s_cnt[3072];
   __shared__ uint32_t s_part[256];
@@ -306,7 +473,11 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
     if (e < nent) {
       const int blk = e / 3, ci = e % 3, c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
       const size_t cell = (size_t)(by0 + blk / bw) * im.w8 + bx0 + blk % bw;
-      cnt = 1u + im.last[c][cell];
+      const uint32_t st = im.strat[cell];
+      if (st & 0x80) {
+        const uint32_t lc = (st & 0x7F) == 5 ? 2u : ((st & 0x7F) == 4 ? 1u : 0u), covered = 1u << (2 * lc);
+        cnt = 1u + (im.nzc[c][cell] ? (uint32_t)im.last[c][cell] + 1u - covered : 0u);
+      }
     }
     s_cnt[e] = cnt;
   }
@@ -330,13 +501,17 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
     const int blk = e / 3, ci = e % 3, c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
     const int bx = blk % bw, by = blk / bw;
     const size_t cell = (size_t)(by0 + by) * im.w8 + bx0 + bx;
+    const uint32_t st = im.strat[cell];
+    if (!(st & 0x80)) continue;
+    const uint32_t lc = (st & 0x7F) == 5 ? 2u : ((st & 0x7F) == 4 ? 1u : 0u), cc = 1u << lc, log2c = 2 * lc, covered = 1u << log2c, size = covered << 6;
     const uint8_t* nzp = im.nz[c];
-    const uint32_t nzeros0 = nzp[cell];
+    const uint32_t nzeros0 = im.nzc[c][cell];
     uint32_t predicted;
     if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)nzp[cell - im.w8];
     else if (by == 0) predicted = nzp[cell - 1];
     else predicted = ((uint32_t)nzp[cell - im.w8] + nzp[cell - 1] + 1) >> 1;
-    const uint32_t block_ctx = c == 1 ? 0u : 7u;   // default block-context map, 8x8 DCT: Y -> 0, X and B -> 7
+    // default block-context map: Y -> 0 (8x8) / 2 (16x16, 32x32); X and B -> 7 / 9
+    const uint32_t block_ctx = (c == 1 ? 0u : 7u) + (lc ? 2u : 0u);
     uint32_t nzc = predicted >= 64 ? 64 : predicted;
     nzc = nzc < 8 ? nzc : 4 + nzc / 2;
     DevToken t;
@@ -348,13 +523,15 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
     atomicAdd(&im.hist_ac[(size_t)t.ctx * kEncSyms + tok], 1u);
     if (!nzeros0) continue;
     const uint32_t histo = nbc * 37 + 458 * block_ctx;
-    const int32_t* q = im.qs[c] + cell * 64;
-    uint32_t nzeros = nzeros0, prev = nzeros0 > 4 ? 0u : 1u;   // size / 16 = 4
+    uint32_t nzeros = nzeros0, prev = nzeros0 > size / 16 ? 0u : 1u;
     const uint32_t lastk = im.last[c][cell];
-    for (uint32_t kk = 1; kk <= lastk; kk++) {
-      const uint32_t fctx = kk < 16 ? kk - 1 : (kk < 32 ? 15 + ((kk - 16) >> 1) : 23 + ((kk - 32) >> 2));
-      t.ctx = histo + ((uint32_t)e_nnz_ctx[nzeros] + fctx) * 2 + prev;
-      t.value = PackSignedD(q[kk]);
+    for (uint32_t kk = covered; kk <= lastk; kk++) {
+      const uint32_t cj = kk >> 6;
+      const int32_t q = im.qs[c][(cell + (size_t)(cj >> lc) * im.w8 + (cj & (cc - 1))) * 64 + (kk & 63)];
+      const uint32_t ks = kk >> log2c;
+      const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 15 + ((ks - 16) >> 1) : 23 + ((ks - 32) >> 2));
+      t.ctx = histo + ((uint32_t)e_nnz_ctx[(nzeros + covered - 1) >> log2c] + fctx) * 2 + prev;
+      t.value = PackSignedD(q);
       out[pos++] = t;
       HybridD(t.value, &tok, &nb, &bits);
       atomicAdd(&im.hist_ac[(size_t)t.ctx * kEncSyms + tok], 1u);
@@ -562,7 +739,7 @@ __device__ __forceinline__ bool LossyStream(const EncImage& im, int st, DevToken
     const int gx = g % im.xlf, gy = g / im.xlf;
     const int bw = min(kLfGroupBlocks, im.w8 - gx * kLfGroupBlocks), bh = min(kLfGroupBlocks, im.h8 - gy * kLfGroupBlocks);
     *modular = true;
-    if (st & 1) { *tok = im.tok_meta + (size_t)g * kMetaTokCap; *n = (uint32_t)(bw * bh); }
+    if (st & 1) { *tok = im.tok_meta + (size_t)g * kMetaTokCap; *n = im.n_meta[g]; }
     else { *tok = im.tok_lf + (size_t)g * kLfTokCap; *n = (uint32_t)(3 * bw * bh); }
     return true;
   }
@@ -622,7 +799,8 @@ __global__ __launch_bounds__(64 * kSectionsPerWg) void enc_sections_kernel(EncIm
     w.PutUniform(4, 3);   // modular group header: global tree, default weighted-predictor parameters, no transforms
     LossyStream(im, 2 * g, &tok, &n, &modular);
     ForwardPass(tok, n, im.stream_state[2 * g], w);
-    w.PutUniform(CeilLog2E((uint32_t)(bw * bh)), (uint32_t)(bw * bh - 1));   // number of varblocks - 1
+    const uint32_t nblocks = im.squares ? im.n_meta[g] / 2 : im.n_meta[g];
+    w.PutUniform(CeilLog2E((uint32_t)(bw * bh)), nblocks - 1);   // number of varblocks - 1
     w.PutUniform(4, 3);
     LossyStream(im, 2 * g + 1, &tok, &n, &modular);
     ForwardPass(tok, n, im.stream_state[2 * g + 1], w);
@@ -751,11 +929,14 @@ void LaunchEncAnalyze(const EncImage& im, hipStream_t s) {
 void LaunchEncFrontEnd(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_xyb_kernel, dim3(GridFor((size_t)im.w * im.h)), dim3(256), 0, s, im);
   hipLaunchKernelGGL(enc_sharpen_pad_kernel, dim3(GridFor((size_t)im.wp * im.hp)), dim3(256), 0, s, im);
-  hipLaunchKernelGGL(enc_block_kernel, dim3((unsigned)((im.w8 * im.h8 + 3) / 4)), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_activity_kernel, dim3(GridFor((size_t)im.w8 * im.h8)), dim3(256), 0, s, im);
+  const unsigned regions = (unsigned)(((im.w8 + 3) / 4) * ((im.h8 + 3) / 4));
+  hipLaunchKernelGGL(enc_strategy_kernel, dim3(GridFor(regions)), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_varblock_kernel, dim3(regions), dim3(256), 0, s, im);
 }
 void LaunchEncTokens(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_lf_tokens_kernel, dim3(64, im.nlf), dim3(256), 0, s, im);
-  hipLaunchKernelGGL(enc_meta_tokens_kernel, dim3(32, im.nlf), dim3(256), 0, s, im);
+  hipLaunchKernelGGL(enc_meta_tokens_kernel, dim3(im.nlf), dim3(1024), 0, s, im);
   hipLaunchKernelGGL(enc_ac_tokens_kernel, dim3(im.ng), dim3(256), 0, s, im);
   if (im.has_alpha) hipLaunchKernelGGL(enc_alpha_tokens_kernel, dim3(32, im.ng), dim3(256), 0, s, im);
 }

@@ -283,7 +283,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   clk.Lap("upload + analysis");
   const uint32_t w = bmp->width, h = bmp->height;
   const size_t npx = (size_t)w * h, npad = (size_t)im.wp * im.hp, ncell = (size_t)im.w8 * im.h8;
-  // ---- 2. quantiser and loop-filter parameters (only distance comes from the options, :319; effort is not used)
+  // ---- 2. quantiser and loop-filter parameters (distance, :319); the effort picks the transform set below
   const float distance = std::max(0.05f, std::min(25.0f, opt->distance));
   EncFrameInfo fi;
   fi.encoding = 0;
@@ -307,10 +307,36 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
     const float w1 = 0.115169525f, w2 = 0.061248592f, div = 1.0f + 4.0f * (w1 + w2);
     for (int c = 0; c < 3; c++) { im.gab_w[c][0] = 1.0f / div; im.gab_w[c][1] = w1 / div; im.gab_w[c][2] = w2 / div; }
   }
+  // effort (JxlEncoderTypes.h:29, passed to the encoder library as its effort setting, Encoder/JxlEncoder.cpp:319-326): the library's
+  // fast settings (1..4) keep every block an 8x8 DCT; from 5 up (7 is the host's default) flat regions get 16x16 / 32x32 DCTs
+  im.squares = opt->effort >= 5 ? 1 : 0;
   const StaticTables& st = GetStaticTables();
-  im.order8 = A.Upload(st.natural_order[0]);
-  im.dq8 = A.Upload(st.dq[0]);
-  im.basis8 = A.Upload(st.basis[0]);
+  {
+    const int order_bucket[3] = {0, 2, 3}, quant_table[3] = {0, 4, 5};   // DCT8, DCT16X16, DCT32X32
+    for (int l = 0; l < 3; l++) {
+      const int N = 8 << l, c = 1 << l;
+      const std::vector<uint16_t>& order = st.natural_order[order_bucket[l]];   // scan position -> stored index kx * N + ky
+      std::vector<uint16_t> inv(order.size());
+      for (size_t k = 0; k < order.size(); k++) inv[order[k]] = (uint16_t)k;
+      im.scan_of[l] = A.Upload(inv);
+      im.dq[l] = A.Upload(st.dq[quant_table[l]]);
+      im.basis[l] = A.Upload(st.basis[l]);
+      std::vector<float> div(st.basis[l]);
+      for (auto& v : div) v = v / (float)N;
+      im.basis_div[l] = A.Upload(div);
+      std::vector<float> small((size_t)c * c);
+      for (int k = 0; k < c; k++)
+        for (int n = 0; n < c; n++) small[(size_t)k * c + n] = (float)((k ? std::sqrt(2.0) : 1.0) * std::cos((2 * n + 1) * k * M_PI / (2.0 * c)));
+      im.bsmall[l] = A.Upload(small);
+      auto resample = [&](int k) {   // coefficient k of an 8c-point DCT from the c-point DCT of the block means
+        if (k == 0) return 1.0;
+        const double t = k * M_PI / (2.0 * c);
+        return 1.0 / (std::cos(t / 2) * std::cos(t / 4) * std::cos(t / 8));
+      };
+      for (int ky = 0; ky < c; ky++)
+        for (int kx = 0; kx < c; kx++) im.rs[l][ky * c + kx] = (float)(resample(ky) * resample(kx));
+    }
+  }
   // ---- 3. planes, front end
   for (int c = 0; c < 3; c++) {
     im.xyb[c] = A.Get<float>(npx);
@@ -318,9 +344,12 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
     im.lfq[c] = A.Get<int32_t>(ncell);
     im.qs[c] = A.Get<int32_t>(ncell * 64);
     im.nz[c] = A.Get<uint8_t>(ncell);
-    im.last[c] = A.Get<uint8_t>(ncell);
+    im.nzc[c] = A.Get<uint16_t>(ncell);
+    im.last[c] = A.Get<uint16_t>(ncell);
   }
   im.rawq = A.Get<int32_t>(ncell);
+  im.act = A.Get<float>(ncell);
+  im.strat = A.Get<uint8_t>(ncell);
   if (im.has_alpha) im.alpha_px = A.Get<int32_t>(npx);
   Progress(progress, 15);
   clk.Lap("allocation");
@@ -333,6 +362,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.tok_ac = A.Get<DevToken>((size_t)im.ng * kAcTokCap);
   if (im.has_alpha) im.tok_alpha = A.Get<DevToken>((size_t)im.ng * kAlphaTokCap);
   im.n_ac = A.Get<uint32_t>(im.ng, true);
+  im.n_meta = A.Get<uint32_t>(im.nlf, true);
   im.hist_mod = A.Get<uint32_t>(kNumEncLeaves * kEncSyms, true);
   im.hist_ac = A.Get<uint32_t>((size_t)kAcContexts * kEncSyms, true);
   LaunchEncTokens(im, s);
@@ -354,7 +384,8 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   WriteTree(MakeEncoderTree((uint32_t)im.nlf), lf_global);
   {
     std::vector<uint8_t> pinned(kNumEncLeaves, 0);
-    pinned[kLeafSharp] = pinned[kLeafCfl] = pinned[kLeafStrategy] = 1;   // constant channels: no token is ever written
+    pinned[kLeafSharp] = pinned[kLeafCfl] = 1;   // constant channels: no token is ever written
+    pinned[kLeafStrategy] = im.squares ? 0 : 1;  // ... and so is the strategy row while every block is an 8x8 DCT
     BuildAndWriteCode(hist_mod.data(), kNumEncLeaves, 8, pinned, lf_global, mcode);
   }
   if (im.has_alpha) lf_global.Write(4, 3);   // global Modular image header: global tree, default predictor, no transforms

@@ -18,17 +18,23 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
+# effort (JxlEncoderTypes.h:29): 1..4 keep every block an 8x8 DCT, from 5 up flat regions get 16x16 / 32x32 DCTs; the oracle's
+# encoder has a matching mode for each (strategy_mode 1 / 4)
+EFFORTS = [(3, 1), (7, 4)]
+
+
+@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "default"])
 @pytest.mark.parametrize("size,seed", [((300, 280), 3), ((520, 400), 4), ((264, 2100), 5)])
-def test_save_image_round_trip_rgba(oracle, size, seed):
+def test_save_image_round_trip_rgba(oracle, size, seed, effort, mode):
     w, h = size
     img = synth(w, h, seed)                       # RGBA with a soft alpha mask: the Rgba path (Encoder/JxlEncoder.cpp:33-77)
-    data = api.save_image(bgra_of(img), distance=1.0)
+    data = api.save_image(bgra_of(img), distance=1.0, effort=effort)
     assert data[:12] == bytes([0, 0, 0, 0xC]) + b"JXL \r\n\x87\n"   # always the container (:201)
     od = oracle.decode(data)
     assert od.pixels.shape == (h, w, 4)
     assert (od.pixels[..., 3] == img[..., 3]).all()                  # alpha is lossless
     ours = psnr(od.pixels[..., :3], img[..., :3])
-    ref = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=1)).pixels   # the oracle's encoder, 8x8 DCT only
+    ref = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=mode)).pixels   # the oracle's encoder, same transform set
     theirs = psnr(ref[..., :3], img[..., :3])
     assert ours > 34.0 and ours > theirs - 0.5, (ours, theirs)
     # the product decoder reads its own files back to what the oracle decodes from them
@@ -37,19 +43,27 @@ def test_save_image_round_trip_rgba(oracle, size, seed):
     assert got.pixels.shape == od.pixels.shape and d.max() <= 1
 
 
-def test_quantised_data_matches_the_oracle_encoder(oracle):
-    """Same pixels through both encoders (8x8 DCT only): quantised LF, quant field and HF coefficients agree except where a
-    float32 rounding difference (cbrt / pow / summation order) flips a value sitting on a quantisation boundary."""
+@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "default"])
+def test_quantised_data_matches_the_oracle_encoder(oracle, effort, mode):
+    """Same pixels through both encoders, same transform set: strategies, quant field, quantised LF and HF coefficients agree except
+    where a float32 rounding difference (cbrt / pow / summation order) flips a value sitting on a decision or quantisation boundary."""
     img = synth(512, 384, 7)
-    a = oracle.decode(api.save_image(bgra_of(img), distance=1.0), want_dump=True)
-    b = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=1), want_dump=True)
-    assert (a.planes["strategy"] == b.planes["strategy"]).all()
-    rq = a.planes["raw_quant"] != b.planes["raw_quant"]
+    a = oracle.decode(api.save_image(bgra_of(img), distance=1.0, effort=effort), want_dump=True)
+    b = oracle.decode(oracle.encode(img, distance=1.0, strategy_mode=mode), want_dump=True)
+    sa, sb = a.planes["strategy"], b.planes["strategy"]
+    same = sa == sb
+    assert same.mean() > 0.995                       # an activity within an ulp of a threshold may tip a region the other way
+    if mode == 4:
+        first = sa[sa >= 0x80] & 0x7F
+        assert (first == 4).sum() > 50 and (first == 5).sum() > 10, np.unique(first, return_counts=True)   # both squares really occur
+    else:
+        assert same.all() and ((sa & 0x7F) == 0).all()
+    rq = (a.planes["raw_quant"] != b.planes["raw_quant"]) | ~same
     assert rq.mean() < 0.01
     for c in range(3):
-        d = np.abs(a.planes["lf_quant"][c].astype(int) - b.planes["lf_quant"][c].astype(int))
+        d = np.abs(a.planes["lf_quant"][c].astype(int) - b.planes["lf_quant"][c].astype(int))[same]
         assert d.max() <= 1 and (d > 0).mean() < 0.01
-    # HF: compare only cells whose quant field agrees
+    # HF: compare only cells whose strategy and quant field agree (the dump holds every varblock's coefficients in its own cells)
     w8 = a.w8
     cells_ok = ~rq.reshape(-1)
     for c in range(3):
@@ -58,6 +72,21 @@ def test_quantised_data_matches_the_oracle_encoder(oracle):
         d = np.abs(qa[cells_ok].astype(int) - qb[cells_ok].astype(int))
         # B is coded after subtracting the dequantised Y (chroma from luma), so it also moves wherever Y flipped
         assert d.max() <= 1 and (d > 0).mean() < (0.015 if c == 2 else 0.004), (c, d.max(), (d > 0).mean())
+
+
+def test_effort_changes_the_transform_set_and_the_rate(oracle):
+    img = synth(768, 512, 23)
+    fast = api.save_image(bgra_of(img), distance=1.0, effort=3)
+    default = api.save_image(bgra_of(img), distance=1.0, effort=7)
+    sf = oracle.decode(fast, want_dump=True).planes["strategy"]
+    sd = oracle.decode(default, want_dump=True).planes["strategy"]
+    assert ((sf & 0x7F) == 0).all() and ((sd & 0x7F) != 0).mean() > 0.2
+    assert len(default) < len(fast)                  # larger transforms on flat regions cost fewer bits
+    for data in (fast, default):
+        got = api.load_image(data)
+        od = oracle.decode(data)
+        assert np.abs(got.pixels.astype(int) - od.pixels.astype(int)).max() <= 1
+        assert psnr(od.pixels[..., :3], img[..., :3]) > 34.0
 
 
 def test_pixel_format_analysis(oracle):

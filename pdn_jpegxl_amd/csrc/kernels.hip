@@ -227,11 +227,83 @@ __global__ void llf_kernel(const DevImage* imgs, const float* basis_small, const
   }
 }
 
+// A 64x64 tile that lies inside ONE varblock of at least 64 points both ways (varblocks are aligned to their size, so it is enough
+// to look at the tile's first cell) takes the matrix-core kernel below; everything else the vector-ALU kernels.
+__device__ __forceinline__ bool GemmTile(const DevImage& im, int tx, int ty) {
+  const uint32_t info = im.cellinfo[(size_t)ty * 8 * im.w8 + tx * 8];
+  return (info & 0xFF) >= 18 && (info & 0xFF) <= 26 && ((info >> 18) & 7) >= 3 && ((info >> 21) & 7) >= 3;
+}
+
+// Both 1-D IDCT passes of such a tile as 64 x R x 64 matrix products on the matrix cores (v_mfma_f32_16x16x4_f32: exact f32
+// products, k-ordered accumulation), R = 64 / 128 / 256: the 128- and 256-point transforms are the largest matrix products of the
+// codec.  Per step of 16 along k, the workgroup stages a 64 x 16 slice of the left operand and a 16 x 64 slice of the right one in
+// LDS (one of them is a slice of the basis, the other a slice of the coefficient / intermediate plane); wavefront w owns output
+// rows 16 w .. 16 w + 15, four 16 x 16 accumulators.  pass 0: tmp = Basis_R^T * coefficients (columns); pass 1: xyb = tmp * Basis_C.
+typedef float __attribute__((ext_vector_type(4))) GF4;
+__global__ __launch_bounds__(256) void idct_gemm_kernel(const DevImage* imgs, const float* basis_all, int pass) {
+  __shared__ float s_a[64 * 17];   // A[m][k], pitch 17
+  __shared__ float s_b[16 * 65];   // B[k][n], pitch 65
+  const DevImage& im = imgs[blockIdx.y];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lq = lane >> 4;
+  FOR_LISTED_TILES(im, tile) {
+    const int tx = tile % im.wt, ty = tile / im.wt;
+    if (!GemmTile(im, tx, ty)) continue;
+    const uint32_t info = im.cellinfo[(size_t)ty * 8 * im.w8 + tx * 8];
+    const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
+    const int K = pass == 0 ? 8 << lcy : 8 << lcx;           // length of the transform along the contracted dimension
+    const int off = pass == 0 ? iy * 8 : ix * 8;              // the tile's first output row / column inside the varblock
+    const float* B = basis_all + ((size_t)K * K - 64) / 3;   // B[k * K + n]
+    const size_t y0 = (size_t)ty * 64, x0 = (size_t)tx * 64;
+    for (int c = 0; c < 3; c++) {
+      const float* in = pass == 0 ? (const float*)im.coef[c] : im.tmp[c];
+      float* out = pass == 0 ? im.tmp[c] : im.xyb[c];
+      GF4 acc[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) acc[s4] = GF4{0.f, 0.f, 0.f, 0.f};
+      for (int k0 = 0; k0 < K; k0 += 16) {
+        __syncthreads();
+        // stage: 1024 elements of each operand, four per thread
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int e = tid + j * 256;
+          if (pass == 0) {
+            // A[m][k] = Basis[k][off + m] (m fastest in memory);  B[k][n] = coefficient row (block row k) x column n of the tile
+            const int m = e & 63, k = e >> 6;
+            s_a[m * 17 + k] = B[(size_t)(k0 + k) * K + off + m];
+            const int n = e & 63;
+            s_b[k * 65 + n] = in[(y0 - (size_t)iy * 8 + k0 + k) * im.wp + x0 + n];
+          } else {
+            // A[m][k] = intermediate row m of the tile x block column k;  B[k][n] = Basis[k][off + n]
+            const int k = e & 15, m = e >> 4;
+            s_a[m * 17 + k] = in[(y0 + m) * im.wp + x0 - (size_t)ix * 8 + k0 + k];
+            const int n = e & 63, kk = e >> 6;
+            s_b[kk * 65 + n] = B[(size_t)(k0 + kk) * K + off + n];
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+          const float a = s_a[(wave * 16 + l16) * 17 + k4 * 4 + lq];
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) acc[s4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, s_b[(k4 * 4 + lq) * 65 + s4 * 16 + l16], acc[s4], 0, 0, 0);
+        }
+      }
+      // lane owns D[4 * lq + r][l16] of each 16 x 16 accumulator
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        float* o = out + (y0 + wave * 16 + 4 * lq) * im.wp + x0 + s4 * 16 + l16;
+        o[0] = acc[s4].x; o[im.wp] = acc[s4].y; o[2 * (size_t)im.wp] = acc[s4].z; o[3 * (size_t)im.wp] = acc[s4].w;
+      }
+    }
+  }
+}
+
 // Vertical 1-D IDCT: thread = (column x, 8-row cell), all three channels.
 __global__ void idct_v_kernel(const DevImage* imgs, const float* basis_all) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
+    if (GemmTile(im, tx, ty)) continue;
     for (int e = threadIdx.x; e < 512; e += blockDim.x) {
       const int x = tx * 64 + (e & 63), by = ty * 8 + (e >> 6);
       if (x >= im.wp || by >= im.h8) continue;
@@ -266,6 +338,7 @@ __global__ void idct_h_kernel(const DevImage* imgs, const float* basis_all) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
+    if (GemmTile(im, tx, ty)) continue;
     for (int e = threadIdx.x; e < 512; e += blockDim.x) {
       const int bx = tx * 8 + (e >> 6), y = ty * 64 + (e & 63);
       if (bx >= im.w8 || y >= im.hp) continue;
@@ -408,7 +481,9 @@ void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis
   hipLaunchKernelGGL(dequant_kernel, g, dim3(256), 0, s, imgs);
   hipLaunchKernelGGL(llf_kernel, g, dim3(64), 0, s, imgs, basis_small, llf_scale);
   hipLaunchKernelGGL(idct_v_kernel, g, dim3(256), 0, s, imgs, basis_all);
+  hipLaunchKernelGGL(idct_gemm_kernel, g, dim3(256), 0, s, imgs, basis_all, 0);
   hipLaunchKernelGGL(idct_h_kernel, g, dim3(256), 0, s, imgs, basis_all);
+  hipLaunchKernelGGL(idct_gemm_kernel, g, dim3(256), 0, s, imgs, basis_all, 1);
   hipLaunchKernelGGL(idct_special_kernel, g, dim3(192), 0, s, imgs, basis_all, basis_small);
 }
 

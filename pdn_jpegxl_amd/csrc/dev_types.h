@@ -197,7 +197,7 @@ struct DevImage {
   uint32_t* status;         // [0] error bits, [1..] debug
 };
 
-constexpr int kBinfoInts = 2 * 1024 + 2 * 65536 + 65536;
+constexpr int kBinfoInts = 2 * 1024 + 2 * 65536 + 65536 + 65536 + 64;   // ... + prefix sums of the block widths (placement)
 constexpr int kWpLfInts = 10 * (65536 + 2);   // widest channel of an LF group section: the block-info rows
 
 struct SectionTask {   // one workgroup's share of sections of one image

@@ -992,7 +992,8 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
 // Predictors of the row-static channels, then the chroma-from-luma / sharpness maps and the varblock placement.
 __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, const SectionTask* tasks) {
   __shared__ int32_t s_carry[4][256];
-  __shared__ uint32_t s_count;
+  __shared__ uint32_t s_count, s_flag;
+  __shared__ uint32_t s_part[256];
   __shared__ uint32_t s_cov[256 * 8];   // coverage bitmap of the LF group's 256 x 256 cells
   const DevImage& im = imgs[tasks[blockIdx.x].image];
   const int g = tasks[blockIdx.x].first;
@@ -1042,59 +1043,106 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
     im.sharp[(size_t)(by0 + y) * im.w8 + bx0 + x] = (uint8_t)sh;
   }
   __syncthreads();   // s_sharp has been consumed: its scratch is reused for the block positions
-  // ---- varblock placement.  By definition serial (each entry goes to the first cell, in raster order, not yet covered),
-  // but only per BLOCK: lane 0 walks a coverage bitmap in LDS (one 32-bit word per 32 cells) and records positions; the
-  // per-cell fan-out (cellinfo / raw quant of every covered cell) is then done by all lanes.
+  // ---- varblock placement: every block goes to the first cell, in raster order, that is not covered yet.  Serial by definition -
+  // and a one-block-at-a-time walk cost 0.4 us per block, 25 ms for an LF group of 65536 8x8 blocks - but only ACROSS rows: the
+  // blocks that start in row y are exactly the next ones of the sequence whose widths add up to the row's free cells, and block j
+  // of them starts at the free cell number (sum of the widths before it).  So: prefix sums of the widths once, then per row every
+  // thread takes one candidate block, finds its cell by a rank-select in the row's coverage words, checks that its cells are
+  // consecutive free ones and marks the rows below it.  One barrier per row.
   int32_t* s_pos = s_sharp;
-  if (tid == 0) s_count = 0;
+  uint32_t* const s_pre = (uint32_t*)(scratch + 2048 + 3 * 65536);   // s_pre[i]: cells taken by the widths of blocks [0, i)
+  if (tid == 0) { s_count = 0; s_flag = 0; }
   for (int i = tid; i < 256 * 8; i += 256) s_cov[i] = 0;
-  __syncthreads();
-  if (wave == 0) {
-    // The walk is serial, but its operands need not be fetched one dependent HBM round trip at a time: the whole wavefront runs the
-    // loop in lockstep (uniform control flow, lane 0 alone stores), every lane holds one entry of the current chunk of 64 block
-    // descriptions - strategy, quant, block shape - fetched together, and the entry of block `num` is a v_readlane away.
-    uint32_t num = 0, chunk = ~0u, packed = 0;
-    const int words = (bw + 31) >> 5;
-    for (int y = 0; y < bh && !(err & kErrBlockLayout); y++) {
-      for (int wi = 0; wi < words; wi++) {
-        for (;;) {
-          uint32_t freebits = ~s_cov[y * 8 + wi];
-          const int lim = min(32, bw - wi * 32);
-          if (lim < 32) freebits &= (1u << lim) - 1;
-          if (!freebits) break;
-          const int xb = __ffs(freebits) - 1;
-          const int x = wi * 32 + xb;
-          if (num >= count) { err |= kErrBlockLayout; break; }
-          if ((num >> 6) != chunk) {
-            chunk = num >> 6;
-            const uint32_t idx = chunk * 64 + lane;
-            const int es = idx < count ? s_info[idx] : -1;
-            const int eq = idx < count ? 1 + s_info[count + idx] : 0;
-            const bool ok = es >= 0 && es < kNumStrategies && eq >= 1 && eq <= 256;
-            packed = ok ? ((uint32_t)es | (uint32_t)eq << 8 | (uint32_t)d_log2cx[es] << 20 | (uint32_t)d_log2cy[es] << 24 | 1u << 31) : 0u;
-          }
-          const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)(num & 63));
-          if (!(e >> 31)) { err |= kErrBlockLayout; break; }
-          const int lcx = (e >> 20) & 7, lcy = (e >> 24) & 7, cx = 1 << lcx, cy = 1 << lcy;
-          if (x + cx > bw || y + cy > bh || xb + cx > 32 || (y & 31) + cy > 32) { err |= kErrBlockLayout; break; }
-          const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1)) << xb;
-          uint32_t clash = 0;
-          for (int iy = 0; iy < cy; iy++) {
-            const uint32_t cur = s_cov[(y + iy) * 8 + wi];
-            clash |= cur & mask;
-            if (lane == 0) s_cov[(y + iy) * 8 + wi] = cur | mask;
-          }
-          if (clash) { err |= kErrBlockLayout; break; }
-          if (lane == 0) s_pos[num] = x | y << 8;
-          num++;
-        }
-        if (err & kErrBlockLayout) break;
-      }
+  {
+    const uint32_t per = (count + 255) / 256, i0 = min(count, (uint32_t)tid * per), i1 = min(count, i0 + per);
+    uint32_t sum = 0;
+    for (uint32_t i = i0; i < i1; i++) {
+      const int es = s_info[i], eq = 1 + s_info[count + i];
+      const bool ok = es >= 0 && es < kNumStrategies && eq >= 1 && eq <= 256;
+      if (!ok) err |= kErrBlockLayout;
+      sum += ok ? 1u << d_log2cx[es] : 1u;
     }
-    if (num != count) err |= kErrBlockLayout;
-    if (lane == 0) s_count = num;
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int i = 0; i < 256; i++) { const uint32_t v = s_part[i]; s_part[i] = acc; acc += v; }
+      s_pre[count] = acc;
+    }
+    __syncthreads();
+    uint32_t base = s_part[tid];
+    for (uint32_t i = i0; i < i1; i++) {
+      const int es = s_info[i];
+      s_pre[i] = base;
+      base += (es >= 0 && es < kNumStrategies) ? 1u << d_log2cx[es] : 1u;
+    }
+    if (err & kErrBlockLayout) atomicOr(&s_flag, 1u);
   }
   __threadfence_block();
+  __syncthreads();
+  uint32_t num = 0;
+  bool layout_bad = false;
+  if (!s_flag) {
+    const int words = (bw + 31) >> 5;
+    for (int y = 0; y < bh; y++) {
+      // the row's free cells: words of free bits and their running counts (every thread computes the same eight)
+      uint32_t pre[9];
+      pre[0] = 0;
+#pragma unroll
+      for (int wi = 0; wi < 8; wi++) {
+        uint32_t fr = 0;
+        if (wi < words) {
+          fr = ~s_cov[y * 8 + wi];
+          const int lim = min(32, bw - wi * 32);
+          if (lim < 32) fr &= (1u << lim) - 1;
+        }
+        pre[wi + 1] = pre[wi] + (uint32_t)__popc(fr);
+      }
+      const uint32_t nfree = pre[8];
+      bool inrow = false, bad = false;
+      if (nfree) {
+        const uint32_t j = num + (uint32_t)tid;
+        uint32_t off = 0;
+        if (j < count) { off = s_pre[j] - s_pre[num]; inrow = off < nfree; }
+        if (inrow) {
+          const int es = s_info[j];
+          const int lcx = d_log2cx[es], lcy = d_log2cy[es], cx = 1 << lcx, cy = 1 << lcy;
+          // rank-select: the word that holds free cell number `off`, then the position of that set bit
+          int wi = 0;
+          uint32_t before = 0;
+#pragma unroll
+          for (int k = 1; k < 8; k++) { const bool past = pre[k] <= off; wi += past ? 1 : 0; before = past ? pre[k] : before; }
+          uint32_t word = ~s_cov[y * 8 + wi];
+          const int lim = min(32, bw - wi * 32);
+          if (lim < 32) word &= (1u << lim) - 1;
+          uint32_t rem = off - before;
+          int xb = 0;
+#pragma unroll
+          for (int sft = 16; sft; sft >>= 1) {
+            const uint32_t c = (uint32_t)__popc((word >> xb) & ((1u << sft) - 1));
+            if (rem >= c) { rem -= c; xb += sft; }
+          }
+          const int x = wi * 32 + xb;
+          const uint32_t mask = (cx == 32 ? 0xFFFFFFFFu : ((1u << cx) - 1)) << xb;
+          if (off + (uint32_t)cx > nfree || x + cx > bw || y + cy > bh || xb + cx > 32 || (y & 31) + cy > 32 || (word & mask) != mask) {
+            bad = true;
+          } else {
+            for (int iy = 1; iy < cy; iy++)   // (row y itself is finished after this step: nobody reads its coverage again)
+              if (atomicOr(&s_cov[(y + iy) * 8 + wi], mask) & mask) bad = true;
+            s_pos[j] = x | y << 8;
+          }
+        }
+      }
+      // both reductions are barriers: the marks of this row are visible to the next, and every thread takes the same exit
+      const int n_row = __syncthreads_count(inrow);
+      if (__syncthreads_or(bad || (nfree && !n_row))) { layout_bad = true; break; }   // (free cells left but no block left)
+      num += (uint32_t)n_row;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (s_flag || layout_bad || num != count) err |= kErrBlockLayout;
+  if (tid == 0) s_count = (err & kErrBlockLayout) ? 0u : num;
   __syncthreads();
   const uint32_t placed = s_count;
   for (uint32_t i = tid; i < placed; i += 256) {

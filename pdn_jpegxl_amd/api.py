@@ -91,6 +91,14 @@ def lib(build_if_missing=True):
         if not build_if_missing:
             raise NativeLibraryMissing(path)
         _build.build()
+    # a library built from other sources than the ones in the tree is refused, not used (and not rebuilt here: this process may already
+    # hold the GPU, e.g. under a profiler)
+    try:
+        built_from = open(_build.manifest_path()).read().strip()
+    except OSError:
+        built_from = None
+    if built_from != _build.source_digest():
+        raise NativeLibraryMissing("%s is stale (built from different sources): run python -m pdn_jpegxl_amd.build" % path)
     try:
         L = C.CDLL(path)
     except OSError as e:

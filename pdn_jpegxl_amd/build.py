@@ -15,6 +15,22 @@ def lib_path():
     return os.path.join(LIBDIR, LIBNAME)
 
 
+def source_digest():
+    """SHA-256 over the sources and headers the library is built from.  build() records it next to the library; api.lib() compares it,
+    because the library is git-ignored yet travels to the GPU box: after an edit a suite could run green against the old binary
+    (file times do not survive the copy, contents do)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def manifest_path():
+    return os.path.join(LIBDIR, "sources.sha256")
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -56,6 +72,8 @@ def build(force=False, verbose=False):
         if os.path.islink(alias) or os.path.exists(alias):
             os.remove(alias)
         os.symlink(LIBNAME, alias)
+    with open(manifest_path(), "w") as f:
+        f.write(source_digest() + "\n")
     return out
 
 

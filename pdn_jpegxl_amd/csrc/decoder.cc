@@ -1400,9 +1400,12 @@ DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, 
         return DecoderStatus_CreateMetadataError;   // :648-651
       }
     }
-    if (f.exif && f.exif_size && !cb->setExif(const_cast<uint8_t*>(f.exif), f.exif_size)) return DecoderStatus_CreateMetadataError;   // :764
-    for (auto& x : f.xml)
-      if (!cb->setXmp(const_cast<uint8_t*>(x.first), x.second)) return DecoderStatus_CreateMetadataError;   // :775-782
+    // metadata boxes in file order, whatever their payload size (the reference reports a box when the library completes it, :756-782)
+    static uint8_t empty_payload[1] = {0};
+    for (auto& b : f.meta_in_order) {
+      uint8_t* p = b.size ? const_cast<uint8_t*>(b.data) : empty_payload;
+      if (!(b.is_exif ? cb->setExif(p, b.size) : cb->setXmp(p, b.size))) return DecoderStatus_CreateMetadataError;
+    }
     // ---- pass 2: the frame (Decoder/JxlDecoder.cpp:217-410)
     JxlHipDecoder* dec = ThreadDecoder();
     const int nch = f.ncolor + (cmyk ? 1 : 0) + (has_alpha ? 1 : 0);   // CMYK: C M Y K [A], inverted for the host on the device (:159-215)

@@ -1206,9 +1206,13 @@ void SplitContainer(const uint8_t* data, size_t size, ParsedFrame& f) {
         type = inner;
       }
       if (!memcmp(type, "Exif", 4)) {
-        if (!f.exif) { f.exif = pl; f.exif_size = n; }   // first Exif box wins (Decoder/JxlDecoder.cpp:697-719)
+        if (!f.have_exif) {   // first Exif box wins, even an empty one (Decoder/JxlDecoder.cpp:697-719)
+          f.have_exif = true; f.exif = pl; f.exif_size = n;
+          f.meta_in_order.push_back(ParsedFrame::MetaBox{true, pl, n});
+        }
       } else if (!memcmp(type, "xml ", 4)) {
         f.xml.emplace_back(pl, n);
+        f.meta_in_order.push_back(ParsedFrame::MetaBox{false, pl, n});
       }
     }
     pos += box;

@@ -72,6 +72,10 @@ struct ParsedFrame {
   bool cs_contiguous = true;
   const uint8_t* exif = nullptr; size_t exif_size = 0;
   std::vector<std::pair<const uint8_t*, size_t>> xml;
+  // the boxes the host is told about, in file order (the first Exif box, every xml box; payloads may be empty)
+  struct MetaBox { bool is_exif; const uint8_t* data; size_t size; };
+  std::vector<MetaBox> meta_in_order;
+  bool have_exif = false;
   std::deque<std::vector<uint8_t>> owned_boxes;   // decompressed `brob` payloads (exif / xml may point into these)
   // ---- image header
   uint32_t xsize = 0, ysize = 0, orientation = 1;

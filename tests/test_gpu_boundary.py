@@ -78,3 +78,25 @@ def test_first_frame_of_an_animation_wins(oracle, lossless):
     assert ani.pixels.shape == one.pixels.shape and (ani.pixels == one.pixels).all()
     if lossless:
         assert (ani.pixels == img).all()
+
+
+def test_metadata_callbacks_follow_box_order_and_empty_payloads(oracle):
+    """Decoder/JxlDecoder.cpp:686-782 reports a box when the library completes it: file order, the first Exif box only, every `xml `
+    box, and a zero-length payload is still reported."""
+    import struct
+    import brob_util
+    plain = oracle.encode(synth(64, 48, 1), exif=b"\0\0\0\0II*\0later", xmp=b"<a/>")
+    head, tail = b"", b""
+    for typ, payload, raw in brob_util.boxes(plain):
+        if typ in (b"Exif", b"xml "):
+            continue
+        if typ in (b"JXL ", b"ftyp"):
+            head += raw
+        else:
+            tail += raw
+    box = lambda t, p: struct.pack(">I4s", 8 + len(p), t) + p
+    # xml first, then an EMPTY Exif box (which wins over the later one), then another xml
+    data = head + box(b"xml ", b"<first/>") + box(b"Exif", b"") + box(b"Exif", b"\0\0\0\0II*\0later") + box(b"xml ", b"<second/>") + tail
+    got = api.load_image(data)
+    assert got.trace == ["setBasicInfo", "setKnownColorProfile", "setXmp", "setExif", "setXmp", "setLayerData"]
+    assert got.exif == b"" and got.xmp == b"<first/>"

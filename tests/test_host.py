@@ -215,3 +215,14 @@ def test_encoder_headers_read_back(w, h, gray, alpha, lossless, epf):
     assert info.num_groups == ((w + 255) // 256) * ((h + 255) // 256)
     assert info.num_lf_groups == ((w + 2047) // 2048) * ((h + 2047) // 2048)
     assert info.gaborish == (0 if lossless else 1) and info.epf_iters == (0 if lossless else epf)
+
+
+def test_a_stale_native_library_is_refused(monkeypatch):
+    """The library is git-ignored but travels to the GPU box: one built from other sources than the tree's must not be used silently."""
+    from pdn_jpegxl_amd import build as B
+    api.lib()
+    monkeypatch.setattr(api, "_lib", None)
+    monkeypatch.setattr(B, "source_digest", lambda: "0" * 64)
+    with pytest.raises(api.NativeLibraryMissing) as e:
+        api.lib()
+    assert "stale" in str(e.value)

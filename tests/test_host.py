@@ -226,3 +226,91 @@ def test_a_stale_native_library_is_refused(monkeypatch):
     with pytest.raises(api.NativeLibraryMissing) as e:
         api.lib()
     assert "stale" in str(e.value)
+
+
+# ---------------------------------------------------------------- hand-assembled headers (no oracle, no product writer)
+class _Bits:
+    """LSB-first bit packer, as the codestream defines it."""
+
+    def __init__(self):
+        self.acc, self.n, self.out = 0, 0, bytearray()
+
+    def put(self, nbits, value):
+        assert 0 <= value < (1 << nbits)
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 0xFF)
+            self.acc >>= 8
+            self.n -= 8
+
+    def align(self):
+        if self.n:
+            self.put(8 - self.n, 0)
+
+    def u32(self, dists, value):
+        """U32 with four (nbits, offset) distributions: the first that can hold the value."""
+        for sel, (nbits, offset) in enumerate(dists):
+            if offset <= value < offset + (1 << nbits):
+                self.put(2, sel)
+                self.put(nbits, value - offset)
+                return
+        raise AssertionError(value)
+
+
+def _hand_built_codestream(xsize, ysize, section_bytes=40):
+    """Signature, SizeHeader, all-default ImageMetadata and transform data, all-default FrameHeader (one VarDCT frame), TOC - written
+    from the published field tables alone."""
+    b = _Bits()
+    b.put(8, 0xFF); b.put(8, 0x0A)
+    ratios = {1: (1, 1), 2: (12, 10), 3: (4, 3), 4: (3, 2), 5: (16, 9), 6: (5, 4), 7: (2, 1)}
+    small = xsize % 8 == 0 and ysize % 8 == 0 and xsize <= 256 and ysize <= 256
+    b.put(1, int(small))
+    size_dists = [(9, 1), (13, 1), (18, 1), (30, 1)]
+    if small:
+        b.put(5, ysize // 8 - 1)
+    else:
+        b.u32(size_dists, ysize)
+    ratio = next((r for r, (n, d) in ratios.items() if ysize * n // d == xsize), 0)
+    b.put(3, ratio)
+    if ratio == 0:
+        if small:
+            b.put(5, xsize // 8 - 1)
+        else:
+            b.u32(size_dists, xsize)
+    b.put(1, 1)      # ImageMetadata.all_default: 8-bit sRGB, XYB encoded, no extra channels
+    b.put(1, 1)      # custom transform data: all default
+    b.align()
+    b.put(1, 1)      # FrameHeader.all_default: regular VarDCT frame, one pass, the only frame
+    groups = -(-xsize // 256) * -(-ysize // 256)
+    lf_groups = -(-xsize // 2048) * -(-ysize // 2048)
+    entries = 1 if groups == 1 else 2 + lf_groups + groups
+    b.put(1, 0)      # TOC not permuted
+    b.align()
+    toc_dists = [(10, 0), (14, 1024), (22, 17408), (30, 4211712)]
+    for _ in range(entries):
+        b.u32(toc_dists, section_bytes)
+    b.align()
+    return bytes(b.out) + bytes(section_bytes * entries), groups, lf_groups
+
+
+@pytest.mark.parametrize("size", [(64, 48), (256, 256), (8, 8), (320, 240), (1920, 1080), (300, 200), (2560, 2048), (5000, 3000), (70000, 9)])
+def test_hand_assembled_headers_and_toc_parse(size):
+    """Size header (small / all four U32 ranges / aspect-ratio codes), default metadata, default frame header and the table of contents
+    written bit by bit from the format's field tables: the product's parser must read back the same geometry."""
+    w, h = size
+    data, groups, lf_groups = _hand_built_codestream(w, h)
+    info = api.peek(data)
+    assert (info.width, info.height) == (w, h)
+    assert (info.num_groups, info.num_lf_groups) == (groups, lf_groups)
+    assert info.num_channels == 3 and not info.has_alpha and info.bytes_per_sample == 1
+    assert (info.xsize_blocks, info.ysize_blocks) == (-(-w // 8), -(-h // 8))
+    assert info.codestream_bytes == len(data)
+    # the same bytes inside the container
+    import struct
+    box = lambda t, p: struct.pack(">I4s", 8 + len(p), t) + p
+    boxed = box(b"JXL ", b"\r\n\x87\n") + box(b"ftyp", b"jxl \0\0\0\0jxl ") + box(b"jxlc", data)
+    assert (api.peek(boxed).width, api.peek(boxed).height) == (w, h)
+    # one bit fewer in the table of contents: the sections no longer fit the file
+    with pytest.raises(api.FormatError):
+        api.peek(data[:-1])

@@ -209,6 +209,28 @@ __device__ __forceinline__ uint32_t AnsSym(LaneBits& b, uint32_t& state, typenam
   return sym;
 }
 
+// The same with the alias entry of the NEXT token requested as soon as the new state is known: its LDS round trip then overlaps the
+// hybrid-uint tail, the predictor arithmetic and the store of the current token instead of heading the next iteration.  `e` holds the
+// entry for the current state on entry (AnsPrefetch) and for the new state on exit; only valid while the cluster stays the same.
+template <bool kLds>
+__device__ __forceinline__ uint64_t AnsPrefetch(uint32_t state, typename AS<kLds>::U64 abase, uint32_t log_alpha) {
+  return abase[(state & 0xFFF) >> (12 - log_alpha)];
+}
+template <bool kLds>
+__device__ __forceinline__ uint32_t AnsSymPf(LaneBits& b, uint32_t& state, typename AS<kLds>::U64 abase, uint32_t log_alpha, uint64_t& e) {
+  const uint32_t le = 12 - log_alpha;
+  const uint32_t res = state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
+  const uint32_t x = (uint32_t)e, y = (uint32_t)(e >> 32);
+  const bool g = pos >= (x & 0xFF);
+  const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
+  const uint32_t off = g ? (y & 0xFFFF) + pos : pos;
+  const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
+  state = __umul24(freq, state >> 12) + off;
+  if (state < 65536u) state = (state << 16) | b.Read(16);
+  e = abase[(state & 0xFFF) >> le];
+  return sym;
+}
+
 // The general symbol reader: prefix codes (canonical code walked one length at a time over the next 15 bits) and LZ77 (a window of
 // decoded values per stream in global memory; copies, special two-dimensional distances).  Compatibility path: correct, not tuned -
 // streams written with these options are decoded several times slower than ANS streams without LZ77.
@@ -353,6 +375,7 @@ __device__ __forceinline__ void LeafRow(LaneBits& b, uint32_t& state, const Code
   const uint32_t const_res = (uint32_t)UnpackSigned((cfg >> 16) & 0xFF) * leaf.b + (uint32_t)leaf.splitval;
   const JXL_GLB int32_t* prow = row - stride;
   int32_t W = y ? (use_rb ? rb[0] : prow[0]) : 0, N = W, NW = W;
+  uint64_t entry = constant_token ? 0 : AnsPrefetch<kLds>(state, abase, tab.log_alpha);
   for (int x = 0; x < w; x++) {
     if ((x & (kTopUpEvery - 1)) == 0) b.TopUp();
     int32_t NE = N;
@@ -370,7 +393,7 @@ __device__ __forceinline__ void LeafRow(LaneBits& b, uint32_t& state, const Code
     uint32_t res;
     if (constant_token) res = const_res;
     else {
-      const uint32_t sym = AnsSym<kLds>(b, state, abase, tab.log_alpha);
+      const uint32_t sym = AnsSymPf<kLds>(b, state, abase, tab.log_alpha, entry);
       res = (uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * leaf.b + (uint32_t)leaf.splitval;
     }
     const int32_t val = (int32_t)(res + guess);   // low 32 bits of the 64-bit reference arithmetic
@@ -686,11 +709,12 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
     }
     // sixteen tokens per top-up of the bit window; no per-token bookkeeping beyond the decode itself
     uint32_t first = 0;
+    uint64_t entry = AnsPrefetch<kLds>(state, abase, tab.log_alpha);
     for (int x0 = 0; x0 < w; x0 += kTopUpEvery) {
       b.TopUp();
       const int xe = min(w, x0 + kTopUpEvery);
       for (int x = x0; x < xe; x++) {
-        const uint32_t sym = AnsSym<kLds>(b, state, abase, tab.log_alpha);
+        const uint32_t sym = AnsSymPf<kLds>(b, state, abase, tab.log_alpha, entry);
         const uint32_t val = (uint32_t)UnpackSigned(HybridTail(b, cfg, sym)) * mul + off + (add_w ? W : 0u);
         row[x] = (int32_t)val;
         W = val;

@@ -421,6 +421,36 @@ struct VarDctEncoder {
       for (auto& v : mi.ch[3].d) v = 4;  // EPF sharpness
       for (int mc = 0; mc < 4; mc++) TokenizeChannel(tree, wp_default, mi, mc, 1 + 2 * nlf + g, meta_tok[g]);
     });
+    // custom coefficient orders: per order bucket and channel, the positions after the LLF ones sorted by how often they are
+    // non-zero in this frame (stable, so unused positions keep their natural order); every pass uses the same orders
+    std::vector<uint32_t> custom_order[kNumOrders][3];
+    uint32_t used_orders = 0;
+    if (p.custom_orders) {
+      std::vector<uint32_t> hits[kNumOrders][3];
+      for (size_t cell = 0; cell < ncell; cell++) {
+        if (!(strategy[cell] & 0x80)) continue;
+        const int s = strategy[cell] & 0x7F, o = kStrategyOrder[s];
+        const std::vector<uint32_t>& nat = NaturalOrder(s);
+        for (int c = 0; c < 3; c++) {
+          if (hits[o][c].empty()) hits[o][c].assign(nat.size(), 0);
+          if (nat.size() != hits[o][c].size()) continue;   // (strategies that share a bucket share its size)
+          for (size_t k = 0; k < nat.size(); k++) hits[o][c][k] += qac[c][cell][nat[k]] != 0;
+        }
+        used_orders |= 1u << o;
+      }
+      for (int o = 0; o < kNumOrders; o++) {
+        if (!(used_orders >> o & 1)) continue;
+        for (int c = 0; c < 3; c++) {
+          const size_t n = hits[o][c].size();
+          size_t llf = 0;
+          for (int s = 0; s < kNumStrategies; s++) if (kStrategyOrder[s] == o) { llf = (size_t)kCoveredX[s] * kCoveredY[s]; break; }
+          std::vector<uint32_t> perm(n);
+          for (size_t k = 0; k < n; k++) perm[k] = (uint32_t)k;
+          std::stable_sort(perm.begin() + llf, perm.end(), [&](uint32_t a, uint32_t b) { return hits[o][c][a] > hits[o][c][b]; });
+          custom_order[o][c] = perm;   // scan position k reads natural position perm[k]
+        }
+      }
+    }
     ParallelFor((int)ng, p.num_threads, [&](int g) {
       int gx = g % f.xsize_groups, gy = g / f.xsize_groups;
       // AC tokens
@@ -442,8 +472,15 @@ struct VarDctEncoder {
           int s = strategy[cell] & 0x7F, cx = kCoveredX[s], cy = kCoveredY[s];
           uint32_t covered = cx * cy, log2c = CeilLog2(covered), size = covered * 64;
           uint32_t ord = kStrategyOrder[s];
-          const uint32_t* ordp = NaturalOrder(s).data();
+          const uint32_t* natp = NaturalOrder(s).data();
+          std::vector<uint32_t> ord_c;
           for (int c : {1, 0, 2}) {
+            const uint32_t* ordp = natp;
+            if (used_orders >> ord & 1) {
+              ord_c.resize(size);
+              for (uint32_t k = 0; k < size; k++) ord_c[k] = natp[custom_order[ord][c][k]];
+              ordp = ord_c.data();
+            }
             std::vector<int32_t> q = qac[c][cell];
             if (np > 1) for (auto& v : q) v = share(v);
             uint32_t nzeros = 0;
@@ -539,7 +576,23 @@ struct VarDctEncoder {
     if (p.custom_quant_tables) hg.Append(dq_bits);
     else hg.Bool(true);                     // default dequant matrices
     hg.Write(CeilLog2(ng), 0);              // num_hf_presets - 1
-    hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);  // used_orders: none
+    auto write_orders = [&]() {
+      hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), used_orders);
+      if (!used_orders) return;
+      std::vector<Token> tok;
+      for (int o = 0; o < kNumOrders; o++) {
+        if (!(used_orders >> o & 1)) continue;
+        size_t llf = 0;
+        for (int s = 0; s < kNumStrategies; s++) if (kStrategyOrder[s] == o) { llf = (size_t)kCoveredX[s] * kCoveredY[s]; break; }
+        for (int c = 0; c < 3; c++) TokenizePermutation(custom_order[o][c], llf, tok);
+      }
+      EncCode code;
+      EncOptions eo;
+      eo.max_clusters = 8;
+      BuildAndWriteCode({&tok}, 8, eo, hg, code);
+      WriteTokens(tok, code, hg);
+    };
+    write_orders();
     std::vector<EncCode> acode(np);
     {   // token counts of the frame's four stream families (bench.py prices the GPU entropy stages per token with them)
       uint64_t n[4] = {0, 0, 0, 0};
@@ -550,7 +603,7 @@ struct VarDctEncoder {
       SetLastEncodeTokenCounts(n);
     }
     for (uint32_t pass = 0; pass < np; pass++) {
-      if (pass) hg.U32(Val(0x5F), Val(0x13), Val(0), Bits(kNumOrders), 0);   // every pass: its coefficient orders (none), then its code
+      if (pass) write_orders();   // every pass: its coefficient orders, then its code
       std::vector<const std::vector<Token>*> acsets;
       for (uint32_t g = 0; g < ng; g++) acsets.push_back(&ac_tok[(size_t)pass * ng + g]);
       EncOptions ao;

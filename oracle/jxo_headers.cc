@@ -462,6 +462,27 @@ void ReadPermutation(BitReader& br, EntropyReader& rd, size_t skip, size_t size,
   }
 }
 
+void TokenizePermutation(const std::vector<uint32_t>& perm, size_t skip, std::vector<Token>& out) {
+  const size_t size = perm.size();
+  std::vector<uint32_t> lehmer(size, 0), temp(size);
+  for (size_t i = 0; i < size; i++) temp[i] = (uint32_t)i;
+  for (size_t i = 0; i < size; i++) {
+    size_t pos = 0;
+    while (temp[pos] != perm[i]) pos++;
+    lehmer[i] = (uint32_t)pos;
+    temp.erase(temp.begin() + pos);
+  }
+  for (size_t i = 0; i < skip; i++) JXO_CHECK(lehmer[i] == 0, "permutation moves a fixed entry");
+  size_t end = size;
+  while (end > skip && lehmer[end - 1] == 0) end--;
+  out.emplace_back(CoeffOrderContext((uint32_t)size), (uint32_t)(end - skip));
+  uint32_t last = 0;
+  for (size_t i = skip; i < end; i++) {
+    out.emplace_back(CoeffOrderContext(last), lehmer[i]);
+    last = lehmer[i];
+  }
+}
+
 void ReadToc(BitReader& br, size_t n, Toc& toc) {
   std::vector<uint32_t> perm;
   bool permuted = br.Bool();

@@ -117,6 +117,9 @@ void ReadToc(BitReader& br, size_t num_entries, Toc& toc);
 void WriteToc(BitWriter& bw, const std::vector<uint32_t>& sizes);
 struct EntropyReader;
 void ReadPermutation(BitReader& br, EntropyReader& rd, size_t skip, size_t size, std::vector<uint32_t>& perm);
+// tokens of a permutation whose first `skip` entries are fixed (Lehmer code; contexts as ReadPermutation reads them)
+struct Token;
+void TokenizePermutation(const std::vector<uint32_t>& perm, size_t skip, std::vector<Token>& out);
 
 // ------------------------------------------------------------------ container
 struct ContainerInfo {

@@ -1075,14 +1075,23 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
 // LF stage of ONE single-section frame on temporary buffers, synchronously: yields the bit position where HfGlobal starts,
 // which the host then parses (ParseHfGlobalAt).  The main pass decodes the (tiny) LF group again with everything in place.
 void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
-  if (f.mcode.use_prefix || f.mcode.lz77)
-    throw ParseError(DecoderStatus_DecodeError, "prefix-coded / LZ77 Modular streams in a frame that fits one group are not supported yet");
   Bump b;
   const size_t cells = (size_t)f.w8 * f.h8;
   const size_t o_img = b.Take(sizeof(DevImage)), o_task = b.Take(sizeof(SectionTask));
   const size_t o_secoff = b.Take(8 * f.sec_off.size()), o_secsize = b.Take(4 * f.sec_size.size());
   const size_t o_tree = b.Take(sizeof(DevTreeNode) * f.tree.size());
   const size_t o_cmap = b.Take(f.mcode.ctx_map.size()), o_cfg = b.Take(4 * f.mcode.cfg.size()), o_alias = b.Take(8 * f.mcode.alias.size());
+  // prefix codes: counts per length, symbol offsets, symbols sorted by code (as the main pass lays them out)
+  std::vector<uint16_t> pfx_counts, pfx_sorted;
+  std::vector<uint32_t> pfx_offs;
+  if (f.mcode.use_prefix)
+    for (auto& pc : f.mcode.prefix) {
+      pfx_counts.insert(pfx_counts.end(), pc.count, pc.count + 16);
+      pfx_offs.push_back((uint32_t)pfx_sorted.size());
+      pfx_sorted.insert(pfx_sorted.end(), pc.sorted.begin(), pc.sorted.end());
+    }
+  const size_t o_pcount = b.Take(2 * std::max<size_t>(1, pfx_counts.size())), o_poff = b.Take(4 * std::max<size_t>(1, pfx_offs.size())),
+               o_psorted = b.Take(2 * std::max<size_t>(1, pfx_sorted.size()));
   const bool resident = dev_file && f.cs_contiguous;
   const size_t o_cs = resident ? 0 : b.Take(f.cs_size + 16);
   const size_t upload = b.off;
@@ -1094,6 +1103,7 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
   const size_t o_binfo = b.Take((size_t)kBinfoInts * 4);
   const size_t o_alpha = b.Take(4 * (size_t)f.xsize * f.ysize);
   const size_t o_wp = f.tree_uses_wp ? b.Take((size_t)kWpLfInts * 4) : 0;
+  const size_t o_lz = f.mcode.lz77 ? b.Take((size_t)4 << 20) : 0;   // the LF group's LZ77 window
   uint8_t* d = nullptr;
   HIP_OK(hipMalloc(&d, b.off));
   std::vector<uint8_t> h(upload, 0);
@@ -1109,6 +1119,16 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
   im.tree = (const DevTreeNode*)(d + o_tree); im.tree_size = (int32_t)f.tree.size();
   im.mcode.ctx_map = d + o_cmap; im.mcode.cfg = (const uint32_t*)(d + o_cfg); im.mcode.alias = (const uint64_t*)(d + o_alias);
   im.mcode.num_ctx = (uint32_t)f.mcode.ctx_map.size(); im.mcode.num_clusters = f.mcode.num_hist; im.mcode.log_alpha = f.mcode.log_alpha;
+  im.mcode.slow = (f.mcode.use_prefix ? 1u : 0u) | (f.mcode.lz77 ? 2u : 0u);
+  if (f.mcode.use_prefix) {
+    im.mcode.pfx_count = (const uint16_t*)(d + o_pcount); im.mcode.pfx_off = (const uint32_t*)(d + o_poff); im.mcode.pfx_sorted = (const uint16_t*)(d + o_psorted);
+  }
+  if (f.mcode.lz77) {
+    im.mcode.lz_min_symbol = f.mcode.lz_min_symbol; im.mcode.lz_min_length = f.mcode.lz_min_length;
+    im.mcode.lz_len_cfg = f.mcode.lz_len.split | f.mcode.lz_len.msb << 4 | f.mcode.lz_len.lsb << 8;
+    im.mcode.lz_dist_cluster = f.mcode.ctx_map.back();
+    im.lz_lf = (uint32_t*)(d + o_lz);
+  }
   im.status = (uint32_t*)(d + o_status); im.lf_end_bits = (uint64_t*)(d + o_end); im.lf_count = (uint32_t*)(d + o_count);
   im.lf_extra = d + o_extra; im.lf_desc = (ChanDesc*)(d + o_desc); im.alpha_desc = (ChanDesc*)(d + o_adesc);
   for (int c = 0; c < 3; c++) im.lfq[c] = (int32_t*)(d + o_lfq[c]);
@@ -1125,12 +1145,19 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
     std::vector<uint32_t> cfgp(f.mcode.cfg.size());
     for (size_t k = 0; k < cfgp.size(); k++) {
       cfgp[k] = f.mcode.cfg[k].split | f.mcode.cfg[k].msb << 4 | f.mcode.cfg[k].lsb << 8;
+      if (f.mcode.use_prefix) {   // one-symbol prefix codes read no bits
+        if (f.mcode.prefix[k].single >= 0) cfgp[k] |= 1u << 12 | (uint32_t)f.mcode.prefix[k].single << 16;
+        continue;
+      }
       const uint64_t e0 = f.mcode.alias[k << f.mcode.log_alpha];
       const uint32_t x0 = (uint32_t)e0, y0 = (uint32_t)(e0 >> 32);
       if ((x0 >> 16) == 0 && (y0 >> 16) == 4096) cfgp[k] |= 1u << 12 | ((x0 >> 8) & 0xFF) << 16;
     }
     memcpy(h.data() + o_cfg, cfgp.data(), 4 * cfgp.size());
   }
+  if (!pfx_counts.empty()) memcpy(h.data() + o_pcount, pfx_counts.data(), 2 * pfx_counts.size());
+  if (!pfx_offs.empty()) memcpy(h.data() + o_poff, pfx_offs.data(), 4 * pfx_offs.size());
+  if (!pfx_sorted.empty()) memcpy(h.data() + o_psorted, pfx_sorted.data(), 2 * pfx_sorted.size());
   memcpy(h.data() + o_alias, f.mcode.alias.data(), 8 * f.mcode.alias.size());
   if (!resident) memcpy(h.data() + o_cs, f.cs, f.cs_size);
   hipError_t e = hipMemcpy(d, h.data(), upload, hipMemcpyHostToDevice);

@@ -1511,9 +1511,6 @@ uint64_t ParseHfGlobalAt(ParsedFrame& f, uint64_t bit_pos) {
   Bits s(f.cs + f.sec_off[0], f.sec_size[0]);
   s.Skip(bit_pos - sec_bits);
   ReadHfGlobal(s, f, f.custom_dq);
-  for (int o = 0; o < kNumOrders; o++)
-    for (int c = 0; c < 3; c++)
-      if (!f.custom_order[o][c].empty()) Fail("custom coefficient orders in single-group frames are not supported on the GPU path yet");
   return sec_bits + s.pos();
 }
 

@@ -269,3 +269,33 @@ def test_progressive_single_group_and_batch(gpu_decoder, oracle):
     outs = gpu_decode(gpu_decoder, files)
     for f, o in zip(files, outs):
         check_pixels(o, oracle.decode(f).pixels)
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(strategy_mode=2, seed=9), dict(num_passes=2), dict(prefix_codes=True, lz77=True), dict(custom_quant_tables=True)],
+                         ids=["plain", "varblocks", "two-passes", "prefix+lz77", "own-tables"])
+def test_custom_coefficient_orders(gpu_decoder, oracle, extra):
+    """Coefficient orders written in the stream (per order bucket and channel: positions sorted by how often they are non-zero, as an
+    encoder that adapts its scan to the image does) instead of the natural zig-zags: the scan lists are built per image."""
+    img = synth(640, 530, 91)
+    data, od = run_case(gpu_decoder, oracle, img, custom_orders=True, **extra)
+    if "custom_quant_tables" not in extra:
+        check_pixels(gpu_decode(gpu_decoder, [data])[0], oracle.decode(oracle.encode(img, **extra)).pixels)
+
+
+def test_custom_coefficient_orders_in_a_one_group_frame(gpu_decoder, oracle):
+    """HfGlobal of a one-section frame is parsed after the LF stage has run on the GPU (its start is only known then); the orders
+    it carries still reach the scan lists."""
+    img = synth(220, 140, 92)
+    run_case(gpu_decoder, oracle, img, custom_orders=True)
+    run_case(gpu_decoder, oracle, img, custom_orders=True, strategy_mode=2, seed=4)
+
+
+@pytest.mark.parametrize("opts", [dict(prefix_codes=True), dict(lz77=True), dict(prefix_codes=True, lz77=True)], ids=["prefix", "lz77", "prefix+lz77"])
+def test_prefix_and_lz77_in_a_one_group_frame(gpu_decoder, oracle, opts):
+    """One-section frames: the LF stage that finds where HfGlobal starts reads the same general symbol streams."""
+    img = synth(230, 150, 93)
+    img[20:90, 30:200, 3] = 255
+    img[100:130, :, :] = img[100:101, :, :]
+    run_case(gpu_decoder, oracle, img, **opts)
+    out = gpu_decode(gpu_decoder, [oracle.encode(img, lossless=True, **opts)])[0]
+    assert (out == img).all()

@@ -200,7 +200,8 @@ struct FrameDecoder {
             for (int32_t t : bctx.lf_thresholds[0]) ix += qx[x] > t;
             for (int32_t t : bctx.lf_thresholds[1]) iy += qy[x] > t;
             for (int32_t t : bctx.lf_thresholds[2]) ib += qb[x] > t;
-            lf_idx[o + x] = (uint8_t)((ix * (bctx.lf_thresholds[1].size() + 1) + iy) * (bctx.lf_thresholds[2].size() + 1) + ib);
+            // [spec, recalled; no external vector] the three bucket indices combine in the order X, B, Y
+            lf_idx[o + x] = (uint8_t)((ix * (bctx.lf_thresholds[2].size() + 1) + ib) * (bctx.lf_thresholds[1].size() + 1) + iy);
           }
         }
       }

@@ -421,6 +421,35 @@ struct VarDctEncoder {
       for (auto& v : mi.ch[3].d) v = 4;  // EPF sharpness
       for (int mc = 0; mc < 4; mc++) TokenizeChannel(tree, wp_default, mi, mc, 1 + 2 * nlf + g, meta_tok[g]);
     });
+    // block contexts from thresholds on the quantised LF (quartiles of Y, zero for X and B) and on the quant field
+    std::vector<uint8_t> lf_idx;
+    if (p.lf_contexts) {
+      std::vector<int32_t> ys(lfq[1]);
+      std::sort(ys.begin(), ys.end());
+      std::vector<int32_t> yt = {ys[ys.size() / 4], ys[ys.size() / 2], ys[3 * ys.size() / 4]};
+      yt.erase(std::unique(yt.begin(), yt.end()), yt.end());
+      bctx.lf_thresholds[0] = {0};
+      bctx.lf_thresholds[1] = yt;
+      bctx.lf_thresholds[2] = {0};
+      bctx.num_lf_ctxs = 2 * (uint32_t)(yt.size() + 1) * 2;
+      bctx.qf_thresholds = {12, 20};
+      const uint32_t nq = 3;
+      bctx.ctx_map.assign((size_t)3 * kNumOrders * nq * bctx.num_lf_ctxs, 0);
+      for (uint32_t cp = 0; cp < 3; cp++)
+        for (uint32_t o = 0; o < (uint32_t)kNumOrders; o++)
+          for (uint32_t q = 0; q < nq; q++)
+            for (uint32_t l = 0; l < bctx.num_lf_ctxs; l++)
+              bctx.ctx_map[((cp * kNumOrders + o) * nq + q) * bctx.num_lf_ctxs + l] = (uint8_t)((cp ? 8 : 0) + (l + 3 * q + (o ? 5 : 0)) % 8);
+      bctx.num_ctxs = 16;
+      lf_idx.assign(ncell, 0);
+      for (size_t cell = 0; cell < ncell; cell++) {
+        uint32_t ix = 0, iy = 0, ib = 0;
+        for (int32_t t : bctx.lf_thresholds[0]) ix += lfq[0][cell] > t;
+        for (int32_t t : bctx.lf_thresholds[1]) iy += lfq[1][cell] > t;
+        for (int32_t t : bctx.lf_thresholds[2]) ib += lfq[2][cell] > t;
+        lf_idx[cell] = (uint8_t)((ix * (bctx.lf_thresholds[2].size() + 1) + ib) * (bctx.lf_thresholds[1].size() + 1) + iy);
+      }
+    }
     // custom coefficient orders: per order bucket and channel, the positions after the LLF ones sorted by how often they are
     // non-zero in this frame (stable, so unused positions keep their natural order); every pass uses the same orders
     std::vector<uint32_t> custom_order[kNumOrders][3];
@@ -490,7 +519,7 @@ struct VarDctEncoder {
             if (bx == 0) predicted = by == 0 ? 32 : row[-32 + bx];
             else if (by == 0) predicted = row[bx - 1];
             else predicted = (row[-32 + bx] + row[bx - 1] + 1) / 2;
-            uint32_t block_ctx = bctx.Context(0, raw_quant[cell], ord, c);
+            uint32_t block_ctx = bctx.Context(lf_idx.empty() ? 0 : lf_idx[cell], raw_quant[cell], ord, c);
             out.emplace_back(bctx.NonZeroContext(predicted, block_ctx), nzeros);
             uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
             for (int iy = 0; iy < cy; iy++)
@@ -528,7 +557,18 @@ struct VarDctEncoder {
     g0.Bool(true);  // LF dequant defaults
     g0.U32(BitsOff(11, 1), BitsOff(11, 2049), BitsOff(12, 4097), BitsOff(16, 8193), global_scale);
     g0.U32(Val(16), BitsOff(5, 1), BitsOff(8, 1), BitsOff(16, 1), quant_lf);
-    g0.Bool(true);  // default block context map
+    if (!p.lf_contexts) {
+      g0.Bool(true);  // default block context map
+    } else {
+      g0.Bool(false);
+      for (int j = 0; j < 3; j++) {
+        g0.Write(4, (uint32_t)bctx.lf_thresholds[j].size());
+        for (int32_t t : bctx.lf_thresholds[j]) g0.U32(Bits(4), BitsOff(8, 16), BitsOff(16, 272), BitsOff(32, 65808), (uint32_t)PackSigned(t));
+      }
+      g0.Write(4, (uint32_t)bctx.qf_thresholds.size());
+      for (uint32_t t : bctx.qf_thresholds) g0.U32(Bits(2), BitsOff(3, 4), BitsOff(5, 12), BitsOff(8, 44), t - 1);
+      EncodeContextMap(g0, bctx.ctx_map);
+    }
     g0.Bool(true);  // default LF chroma-from-luma
     g0.Bool(true);  // has global tree
     WriteTree(g0, tree);

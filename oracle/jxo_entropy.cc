@@ -312,6 +312,29 @@ void DecodeContextMap(BitReader& br, std::vector<uint8_t>& map, uint32_t* num_hi
   *num_hist = mx + 1;
 }
 
+void EncodeContextMap(BitWriter& bw, const std::vector<uint8_t>& map) {
+  uint32_t num_hist = 0;
+  for (auto m : map) num_hist = std::max<uint32_t>(num_hist, m + 1u);
+  if (num_hist <= 8 && map.size() <= 64) {
+    int bits = num_hist <= 1 ? 0 : CeilLog2(num_hist);
+    bw.Write(1, 1);
+    bw.Write(2, bits);
+    for (auto m : map) bw.Write(bits, m);
+    return;
+  }
+  bw.Write(1, 0);  // not simple
+  bw.Write(1, 0);  // no move-to-front
+  std::vector<Token> mt;
+  for (auto m : map) mt.emplace_back(0, m);
+  EncOptions mo;
+  mo.cfg = HybridUintConfig(4, 2, 0);
+  mo.top_level = false;
+  EncCode mc;
+  std::vector<const std::vector<Token>*> sets = {&mt};
+  BuildAndWriteCode(sets, 1, mo, bw, mc);
+  WriteTokens(mt, mc, bw);
+}
+
 void DecodeHistograms(BitReader& br, size_t num_contexts, EntropyCode& code, bool disallow_lz77) {
   code = EntropyCode();
   code.lz77 = br.Bool();

@@ -62,6 +62,7 @@ void ReadHistogram(BitReader& br, std::vector<int32_t>& counts);
 void InitAliasTable(std::vector<int32_t> dist, uint32_t log_alpha, std::vector<AliasEntry>& out);
 void ReadPrefixCode(BitReader& br, uint32_t alphabet_size, PrefixCode& pc);
 void DecodeContextMap(BitReader& br, std::vector<uint8_t>& map, uint32_t* num_hist);
+void EncodeContextMap(BitWriter& bw, const std::vector<uint8_t>& map);   // a context map on its own (block-context map of LfGlobal)
 void DecodeHistograms(BitReader& br, size_t num_contexts, EntropyCode& code, bool disallow_lz77 = false);
 
 struct EntropyReader {

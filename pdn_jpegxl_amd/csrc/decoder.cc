@@ -795,6 +795,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.num_block_ctx = f.num_block_ctx;
     memcpy(d.block_ctx_map, f.block_ctx_map.data(), std::min(sizeof(d.block_ctx_map), f.block_ctx_map.size()));
     d.n_qf = (int32_t)f.qf_thr.size();
+    d.num_lf_ctx = 1;
+    for (int j = 0; j < 3; j++) {
+      d.n_lf_thr[j] = (int32_t)std::min<size_t>(15, f.lf_thr[j].size());
+      for (int k = 0; k < d.n_lf_thr[j]; k++) d.lf_thr[j][k] = f.lf_thr[j][k];
+      d.num_lf_ctx *= d.n_lf_thr[j] + 1;
+    }
     d.custom_orders = 0;
     for (size_t k = 0; k < f.qf_thr.size() && k < 15; k++) d.qf_thr[k] = f.qf_thr[k];
     for (int o = 0; o < kNumOrders; o++)

@@ -95,7 +95,12 @@ struct DevImage {
   // HF
   DevCode acode;
   int32_t num_presets, num_block_ctx;
-  uint8_t block_ctx_map[39 * 16];   // [(c'*13 + ord) * (nqf+1) + qf_idx]
+  uint8_t block_ctx_map[39 * 64];   // [((c'*13 + ord) * (nqf+1) + qf_idx) * num_lf_ctx + lf_idx]; (nqf+1) * num_lf_ctx <= 64
+  // block contexts may also depend on the quantised LF of the block's first cell: per channel (X, Y, B) the number of thresholds it
+  // exceeds; the three indices combine in the order X, B, Y  [spec, recalled; no external vector]
+  int32_t lf_thr[3][15];
+  int32_t n_lf_thr[3];
+  int32_t num_lf_ctx;
   uint32_t qf_thr[15];
   int32_t n_qf;
   int32_t custom_orders;    // any non-natural coefficient order in this frame

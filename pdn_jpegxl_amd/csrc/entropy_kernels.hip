@@ -1217,11 +1217,20 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
       const uint32_t rq = im.rawq[(size_t)(by0 + by) * im.w8 + bx0 + bx];
       uint32_t qf_idx = 0;
       for (int i = 0; i < n_qf; i++) qf_idx += rq > im.qf_thr[i];
+      uint32_t lf_idx = 0;
+      if (im.num_lf_ctx > 1) {   // thresholds on the quantised LF of the block's first cell; X, B, Y order of combination
+        const size_t cell = (size_t)(by0 + by) * im.w8 + bx0 + bx;
+        uint32_t ix = 0, iy = 0, ib = 0;
+        for (int i = 0; i < im.n_lf_thr[0]; i++) ix += im.lfq[0][cell] > im.lf_thr[0][i];
+        for (int i = 0; i < im.n_lf_thr[1]; i++) iy += im.lfq[1][cell] > im.lf_thr[1][i];
+        for (int i = 0; i < im.n_lf_thr[2]; i++) ib += im.lfq[2][cell] > im.lf_thr[2][i];
+        lf_idx = (ix * (uint32_t)(im.n_lf_thr[2] + 1) + ib) * (uint32_t)(im.n_lf_thr[1] + 1) + iy;
+      }
       uint32_t ctxs = 0;
       for (int ci = 0; ci < 3; ci++) {
         const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
         const uint32_t cprime = c < 2 ? (c ^ 1) : 2;
-        ctxs |= ((uint32_t)im.block_ctx_map[(cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx] & 31u) << (5 * ci);
+        ctxs |= ((uint32_t)im.block_ctx_map[((cprime * kNumOrders + ord) * (n_qf + 1) + qf_idx) * im.num_lf_ctx + lf_idx] & 31u) << (5 * ci);
       }
       list[pos] = (uint32_t)bx | (uint32_t)by << 5 | lcx << 10 | lcy << 13 | ctxs << 16;
     }

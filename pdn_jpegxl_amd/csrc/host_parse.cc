@@ -737,14 +737,15 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
       size_t nlf_ctx = 1;
       for (int j = 0; j < 3; j++) {
         uint32_t n = r.u(4);
-        for (uint32_t i = 0; i < n; i++) r.U32(B(4), B(8, 16), B(16, 272), B(32, 65808));
+        f.lf_thr[j].resize(n);
+        for (auto& t : f.lf_thr[j]) { const uint32_t u = r.U32(B(4), B(8, 16), B(16, 272), B(32, 65808)); t = (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
         nlf_ctx *= n + 1;
       }
-      REQUIRE(nlf_ctx == 1, "LF-threshold block contexts are not supported on the GPU path yet");
       uint32_t nqf = r.u(4);
       f.qf_thr.resize(nqf);
       for (auto& t : f.qf_thr) t = r.U32(B(2), B(3, 4), B(5, 12), B(8, 44)) + 1;
-      f.block_ctx_map.assign(39 * (nqf + 1), 0);
+      REQUIRE(nlf_ctx * (nqf + 1) <= 64, "block-context map too large");
+      f.block_ctx_map.assign(39 * (nqf + 1) * nlf_ctx, 0);
       ReadContextMap(r, f.block_ctx_map, &f.num_block_ctx);
       REQUIRE(f.num_block_ctx <= 16, "too many block contexts");
     }

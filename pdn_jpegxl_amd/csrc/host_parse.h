@@ -110,6 +110,7 @@ struct ParsedFrame {
   uint32_t global_scale = 1, quant_lf = 16;
   std::vector<uint8_t> block_ctx_map;
   std::vector<uint32_t> qf_thr;
+  std::vector<int32_t> lf_thr[3];   // LF thresholds of the block-context map (X, Y, B)
   uint32_t num_block_ctx = 15;
   uint32_t color_factor = 84;
   float base_x = 0.f, base_b = 1.f;

@@ -299,3 +299,14 @@ def test_prefix_and_lz77_in_a_one_group_frame(gpu_decoder, oracle, opts):
     run_case(gpu_decoder, oracle, img, **opts)
     out = gpu_decode(gpu_decoder, [oracle.encode(img, lossless=True, **opts)])[0]
     assert (out == img).all()
+
+
+@pytest.mark.parametrize("extra", [dict(), dict(strategy_mode=2, seed=6), dict(num_passes=2, custom_orders=True)], ids=["plain", "varblocks", "passes+orders"])
+def test_block_contexts_from_lf_and_quant_field_thresholds(gpu_decoder, oracle, extra):
+    """A block-context map that depends on the quantised LF of the block (thresholds per channel) and on the quant field, as adaptive
+    encoders write it, instead of the default map.  [How the three LF indices combine is recalled from the format, not pinned.]"""
+    img = synth(700, 520, 95)
+    data, od = run_case(gpu_decoder, oracle, img, lf_contexts=True, **extra)
+    check_pixels(gpu_decode(gpu_decoder, [data])[0], oracle.decode(oracle.encode(img, **extra)).pixels)
+    small = synth(210, 150, 96)
+    run_case(gpu_decoder, oracle, small, lf_contexts=True)

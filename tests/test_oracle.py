@@ -224,7 +224,8 @@ def test_named_colour_encodings_round_trip(oracle, colour):
 
 @pytest.mark.parametrize("opts", [dict(prefix_codes=True), dict(lz77=True), dict(prefix_codes=True, lz77=True), dict(custom_quant_tables=True),
                                   dict(num_passes=2), dict(num_passes=3), dict(num_passes=3, prefix_codes=True, lz77=True),
-                                  dict(custom_orders=True), dict(custom_orders=True, num_passes=2)])
+                                  dict(custom_orders=True), dict(custom_orders=True, num_passes=2), dict(lf_contexts=True),
+                                  dict(lf_contexts=True, custom_orders=True, prefix_codes=True)])
 def test_stream_coding_variants_decode_to_the_same_pixels(oracle, opts):
     """Prefix codes, LZ77 and progressive passes change how the same quantised data is written, never the data: the decode equals
     the plain frame's.  (Explicit quantisation tables do change the weights: only a round trip is required there.)"""

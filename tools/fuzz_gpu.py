@@ -18,7 +18,12 @@ streams = [O.encode(img, distance=1.0), O.encode(img, distance=2.0, strategy_mod
            O.encode(img, lossless=True, lossless_squeeze=True), O.encode(synth(64, 48, 5)),
            O.encode(img.astype(np.uint16) * 257, distance=1.0, bits=16, orientation=6), O.encode(img.astype(np.uint16) * 257, lossless=True, bits=16),
            O.encode((img / 255.0).astype(np.float32), lossless=True, float_samples=32, lossless_predictor=5, lossless_tree=1),
-           O.encode(img, distance=1.5, colour=4)]
+           O.encode(img, distance=1.5, colour=4),
+           # round-2 stream features
+           O.encode(img, distance=1.0, prefix_codes=True, lz77=True), O.encode(img, distance=1.0, num_passes=3, custom_orders=True),
+           O.encode(img, distance=1.0, strategy_mode=2, seed=8, lf_contexts=True, custom_quant_tables=True),
+           O.encode(synth(200, 140, 6), distance=1.0, lf_contexts=True, custom_orders=True, prefix_codes=True),
+           O.encode(img, lossless=True, prefix_codes=True, lz77=True), O.encode(img[..., :3], lossless=True, cmyk=False, icc=None)]
 counts = {}
 for si, data in enumerate(streams):
     for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 25):

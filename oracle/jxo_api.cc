@@ -139,6 +139,7 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.custom_quant_tables = (g_next_flags & 1) != 0;
     p.custom_orders = (g_next_flags & 32) != 0;
     p.lf_contexts = (g_next_flags & 64) != 0;
+    p.palette = (g_next_flags & 128) != 0;
     p.num_passes = (g_next_flags & 16) ? 3 : ((g_next_flags & 8) ? 2 : 1);
     const uint32_t g_next_flags_entropy = g_next_flags;
     g_next_flags = 0;

@@ -74,6 +74,7 @@ struct EncodeParams {
   int float_samples = 0;        // 0: integer samples; 16 / 32: binary16 / binary32 samples (input arrays of that float type)
   std::vector<uint8_t> icc;     // embedded ICC profile instead of the enumerated colour encoding
   int num_passes = 1;                 // lossy: 2 or 3 = progressive passes (coefficient bits split by the shifts 1 / 2, 1)
+  bool palette = false;               // lossless: colour (+ alpha) channels through a Palette transform when the image has at most 1024 colours
   bool lf_contexts = false;           // lossy: a block-context map with LF thresholds (quartiles of the quantised LF) and two quant-field thresholds
   bool custom_orders = false;         // lossy: coefficient orders sorted by how often each position is non-zero (per order bucket and channel)
   bool custom_quant_tables = false;   // lossy: every dequantisation table written explicitly (parameters scaled per table by `seed`)

@@ -685,7 +685,9 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
   }
   GroupHeader gh_global;
   gh_global.use_global_tree = true;
-  if (ncolor == 3 && !m.exp_bits) ForwardRCT(full, 0, 6);   // float samples are coded as bit patterns: no colour transform on those
+  bool paletted = false;
+  if (p.palette && !m.exp_bits) paletted = ForwardPalette(full, 0, (uint32_t)nch, 1024);   // colour and alpha together, as one index channel
+  if (!paletted && ncolor == 3 && !m.exp_bits) ForwardRCT(full, 0, 6);   // float samples are coded as bit patterns: no colour transform on those
   if (p.lossless_squeeze) {
     std::vector<SqueezeParams> sp;
     DefaultSqueezeParams(full, sp);
@@ -697,7 +699,7 @@ std::vector<uint8_t> EncodeLosslessFrame(const ImageMetadata& m, FrameHeader& f,
   const uint32_t nlf = f.num_lf_groups, ng = f.num_groups;
   const int gd = f.group_dim;
   // which channels are coded globally
-  size_t first_group_channel = 0;
+  size_t first_group_channel = (size_t)full.nb_meta;   // meta channels (a palette) always travel in the global stream
   for (; first_group_channel < full.ch.size(); first_group_channel++)
     if (full.ch[first_group_channel].w > gd || full.ch[first_group_channel].h > gd) break;
   std::vector<Token> global_tok;

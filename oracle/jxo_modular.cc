@@ -1,5 +1,7 @@
 // ORACLE — test infrastructure only (see jxo_common.h header).
 #include "jxo_modular.h"
+#include <map>
+#include <set>
 #include <deque>
 
 namespace jxo {
@@ -59,7 +61,11 @@ void WriteGroupHeader(BitWriter& bw, const GroupHeader& h) {
       bw.U32(kBeginC[0], kBeginC[1], kBeginC[2], kBeginC[3], t.begin_c);
       bw.U32(Val(6), Bits(2), BitsOff(4, 2), BitsOff(6, 10), t.rct_type);
     } else if (t.id == 1) {
-      throw Error("palette transform not written by this encoder");
+      bw.U32(kBeginC[0], kBeginC[1], kBeginC[2], kBeginC[3], t.begin_c);
+      bw.U32(Val(1), Val(3), Val(4), BitsOff(13, 1), t.num_c);
+      bw.U32(BitsOff(8, 0), BitsOff(10, 256), BitsOff(12, 1280), BitsOff(16, 5376), t.nb_colors);
+      bw.U32(Val(0), BitsOff(8, 1), BitsOff(10, 257), BitsOff(16, 1281), t.nb_deltas);
+      bw.Write(4, t.predictor);
     } else {
       bw.U32(Val(0), BitsOff(4, 1), BitsOff(6, 9), BitsOff(8, 41), (uint32_t)t.squeezes.size());
       for (auto& s : t.squeezes) {
@@ -464,7 +470,15 @@ void MetaApplyTransforms(ModularImage& img, const GroupHeader& h) {
         JXO_CHECK(a.w == b.w && a.h == b.h, "RCT channel size mismatch");
       }
     } else if (t.id == 1) {
-      throw Error("Palette transform is not supported by the oracle yet");
+      // Palette: num_c channels become one channel of indices; the colours travel in a meta channel (nb_colors x num_c) put first
+      CheckRange(img, t.begin_c, t.num_c);
+      JXO_CHECK(t.begin_c >= (uint32_t)img.nb_meta, "palette of meta channels is not supported");
+      JXO_CHECK(t.nb_deltas == 0, "delta palettes are not supported");
+      const Channel& a = img.ch[t.begin_c];
+      for (uint32_t i = 1; i < t.num_c; i++) JXO_CHECK(img.ch[t.begin_c + i].w == a.w && img.ch[t.begin_c + i].h == a.h, "palette channel size mismatch");
+      img.ch.erase(img.ch.begin() + t.begin_c + 1, img.ch.begin() + t.begin_c + t.num_c);
+      img.ch.insert(img.ch.begin(), Channel((int)t.nb_colors, (int)t.num_c, -1, -1));
+      img.nb_meta++;
     } else {
       MetaSqueeze(img, t.squeezes);
     }
@@ -654,6 +668,43 @@ void ForwardRCT(ModularImage& img, uint32_t begin_c, uint32_t rct_type) {
   img.transforms.push_back(t);
 }
 
+bool ForwardPalette(ModularImage& img, uint32_t begin_c, uint32_t num_c, size_t max_colors) {
+  CheckRange(img, begin_c, num_c);
+  const int w = img.ch[begin_c].w, h = img.ch[begin_c].h;
+  std::vector<std::vector<int32_t>> colors;
+  {
+    std::set<std::vector<int32_t>> seen;
+    std::vector<int32_t> px(num_c);
+    for (int y = 0; y < h; y++)
+      for (int x = 0; x < w; x++) {
+        for (uint32_t c = 0; c < num_c; c++) px[c] = img.ch[begin_c + c].Row(y)[x];
+        seen.insert(px);
+        if (seen.size() > max_colors) return false;
+      }
+    colors.assign(seen.begin(), seen.end());   // lexicographic order
+  }
+  std::map<std::vector<int32_t>, int32_t> index;
+  for (size_t i = 0; i < colors.size(); i++) index[colors[i]] = (int32_t)i;
+  Channel pal((int)colors.size(), (int)num_c, -1, -1);
+  for (size_t i = 0; i < colors.size(); i++)
+    for (uint32_t c = 0; c < num_c; c++) pal.Row((int)c)[i] = colors[i][c];
+  Channel idx(w, h, img.ch[begin_c].hshift, img.ch[begin_c].vshift);
+  std::vector<int32_t> px(num_c);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      for (uint32_t c = 0; c < num_c; c++) px[c] = img.ch[begin_c + c].Row(y)[x];
+      idx.Row(y)[x] = index[px];
+    }
+  img.ch.erase(img.ch.begin() + begin_c, img.ch.begin() + begin_c + num_c);
+  img.ch.insert(img.ch.begin() + begin_c, idx);
+  img.ch.insert(img.ch.begin(), pal);
+  img.nb_meta++;
+  Transform t;
+  t.id = 1; t.begin_c = begin_c; t.num_c = num_c; t.nb_colors = (uint32_t)colors.size(); t.nb_deltas = 0; t.predictor = 0;
+  img.transforms.push_back(t);
+  return true;
+}
+
 void ForwardSqueeze(ModularImage& img, const std::vector<SqueezeParams>& params_in) {
   std::vector<SqueezeParams> params = params_in;
   if (params.empty()) DefaultSqueezeParams(img, params);
@@ -689,7 +740,22 @@ void UndoTransforms(ModularImage& img) {
         img.ch.erase(img.ch.begin() + offset, img.ch.begin() + offset + s.num_c);
       }
     } else {
-      throw Error("Palette transform is not supported by the oracle yet");
+      // inverse Palette: look every index up (indices outside the stored palette - implicit and delta colours - are not supported)
+      const Channel pal = img.ch[0];
+      const uint32_t ic = t.begin_c + 1;   // the index channel, after the meta channel in front
+      const Channel idx = img.ch[ic];
+      std::vector<Channel> out;
+      for (uint32_t c = 0; c < t.num_c; c++) out.emplace_back(idx.w, idx.h, idx.hshift, idx.vshift);
+      for (int y = 0; y < idx.h; y++)
+        for (int x = 0; x < idx.w; x++) {
+          const int32_t i = idx.Row(y)[x];
+          JXO_CHECK(i >= 0 && i < pal.w, "palette index outside the stored palette");
+          for (uint32_t c = 0; c < t.num_c; c++) out[c].Row(y)[x] = pal.Row((int)c)[i];
+        }
+      img.ch.erase(img.ch.begin() + ic);
+      img.ch.insert(img.ch.begin() + ic, out.begin(), out.end());
+      img.ch.erase(img.ch.begin());
+      img.nb_meta--;
     }
   }
   img.transforms.clear();

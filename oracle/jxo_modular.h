@@ -67,6 +67,8 @@ void UndoTransforms(ModularImage& img);
 // Forward transforms for the encoder (applies and records in img.transforms).
 void ForwardRCT(ModularImage& img, uint32_t begin_c, uint32_t rct_type);
 void ForwardSqueeze(ModularImage& img, const std::vector<SqueezeParams>& params);
+// channels [begin_c, begin_c + num_c) -> one index channel + a palette meta channel in front; false (nothing changed) above max_colors
+bool ForwardPalette(ModularImage& img, uint32_t begin_c, uint32_t num_c, size_t max_colors);
 void DefaultSqueezeParams(const ModularImage& img, std::vector<SqueezeParams>& out);
 
 // Decodes one channel with an already-initialised reader.

@@ -654,7 +654,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   int nlf_t = 0, npass_t = 0, nalpha_t = 0, nlf_ans_t = 0, nmod_t = 0, max_groups = 1, max_mod_groups = 1;
   size_t lds_mod = 0, max_mod_pixels = 1;
   int max_mod_coded = 1;
-  struct ModLaunch { int kind; int32_t *a, *b, *c; int aw, ah, rw, rh, type; };
+  struct ModLaunch { int kind; int32_t *a, *b, *c; int aw, ah, rw, rh, type; int32_t* out[4]; int nout; uint32_t* status; };
   std::vector<ModLaunch> mod_ops;
   uint8_t* wz = d_ws;
   uint8_t* wr = d_ws + zero_bytes;
@@ -752,7 +752,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.mod_data_bits = f.mod_data_bits;
       // without Squeeze (at most four colour transforms) the RCTs are undone inside modular_out_kernel; otherwise every inverse
       // operation is its own launch (below) and the output kernel only clamps and interleaves
-      const bool inline_rct = !f.mod_has_squeeze && f.mod_transforms.size() <= 4;
+      const bool inline_rct = !f.mod_has_squeeze && !f.mod_has_palette && f.mod_transforms.size() <= 4;
       d.mod_ntr = inline_rct ? (int32_t)f.mod_transforms.size() : 0;
       for (int t = 0; t < d.mod_ntr; t++) { d.mod_tr[t][0] = (int32_t)f.mod_transforms[t].begin_c; d.mod_tr[t][1] = (int32_t)f.mod_transforms[t].rct_type; }
       for (int c = 0; c < d.mod_nch; c++) d.mod_plane[c] = (int32_t*)(wr + l.mod_planes[c]);
@@ -770,8 +770,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       if (!inline_rct)
         for (auto& op : f.mod_ops) {
           const ParsedFrame::ModPlane &pa = f.mod_planes[op.a], &pb = f.mod_planes[op.b];
-          mod_ops.push_back(ModLaunch{op.kind, (int32_t*)(wr + l.mod_planes[op.a]), (int32_t*)(wr + l.mod_planes[op.b]),
-                                      (int32_t*)(wr + l.mod_planes[op.c]), pa.w, pa.h, pb.w, pb.h, op.type});
+          ModLaunch ml{op.kind, (int32_t*)(wr + l.mod_planes[op.a]), (int32_t*)(wr + l.mod_planes[op.b]),
+                       (int32_t*)(wr + l.mod_planes[op.c]), pa.w, pa.h, pb.w, pb.h, op.type, {nullptr, nullptr, nullptr, nullptr}, op.nout, (uint32_t*)(wz + l.z_status)};
+          for (int k = 0; k < op.nout && k < 4; k++) ml.out[k] = (int32_t*)(wr + l.mod_planes[op.out[k]]);
+          mod_ops.push_back(ml);
         }
       d.status = (uint32_t*)(wz + l.z_status);
       status_off[i] = l.z_status;
@@ -1049,7 +1051,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
     LaunchModularAns(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
                      max_mod_coded, mod_lanes, mod_rb, mod_wp_lds, stream);
-    for (auto& op : mod_ops) LaunchModularOp(op.kind, op.a, op.b, op.c, op.aw, op.ah, op.rw, op.rh, op.type, stream);
+    for (auto& op : mod_ops) {
+      if (op.kind == 3) LaunchModularPalette(op.a, op.b, op.out, op.nout, op.type, op.rw, op.rh, op.status, stream);   // a: palette, b: indices (rw x rh)
+      else LaunchModularOp(op.kind, op.a, op.b, op.c, op.aw, op.ah, op.rw, op.rh, op.type, stream);
+    }
     LaunchModularOut(d_imgs, n, max_mod_pixels, stream);
     Mark("modular", stream, 2);
   }

@@ -1849,6 +1849,28 @@ void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int a
   }
 }
 
+struct PaletteOut { int32_t* p[4]; };
+__global__ void palette_inverse_kernel(const int32_t* palette, const int32_t* index, PaletteOut out, int nout, int nb_colors, size_t n, uint32_t* status) {
+  bool bad = false;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int32_t idx = index[i];
+    const bool ok = idx >= 0 && idx < nb_colors;
+    bad |= !ok;
+    for (int k = 0; k < nout; k++) out.p[k][i] = ok ? palette[(size_t)k * nb_colors + idx] : 0;
+  }
+  if (bad) atomicOr(status, (uint32_t)kErrUnsupportedHeader);
+}
+void LaunchModularPalette(const int32_t* palette, const int32_t* index, int32_t* const* out, int nout, int nb_colors, int w, int h, uint32_t* status,
+                          hipStream_t s) {
+  const size_t n = (size_t)w * h;
+  if (!n || nout <= 0) return;
+  PaletteOut o;
+  for (int k = 0; k < 4; k++) o.p[k] = k < nout ? out[k] : nullptr;
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(palette_inverse_kernel, dim3((unsigned)blocks), dim3(256), 0, s, palette, index, o, nout, nb_colors, n, status);
+}
+
 void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s) {
   size_t b = (max_pixels + 255) / 256;
   if (b > 8192) b = 8192;

@@ -775,8 +775,15 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
       ParsedFrame::ModTransform t;
       t.id = r.u(2);
       REQUIRE(t.id != 3, "invalid modular transform");
-      REQUIRE(t.id != 1, "Palette transforms are not decoded on the GPU path yet");
-      if (t.id == 0) {
+      if (t.id == 1) {
+        t.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
+        t.num_c = r.U32(V(1), V(3), V(4), B(13, 1));
+        t.nb_colors = r.U32(B(8), B(10, 256), B(12, 1280), B(16, 5376));
+        t.nb_deltas = r.U32(V(0), B(8, 1), B(10, 257), B(16, 1281));
+        t.predictor = r.u(4);
+        REQUIRE(t.nb_deltas == 0, "delta palettes are not supported yet");
+        REQUIRE(t.num_c >= 1 && t.num_c <= 4 && t.nb_colors >= 1, "palettes of more than four channels are not supported yet");
+      } else if (t.id == 0) {
         t.begin_c = r.U32(B(3), B(6, 8), B(10, 72), B(13, 1096));
         t.rct_type = r.U32(V(6), B(2), B(4, 2), B(6, 10));
         REQUIRE(t.rct_type < 42, "reversible colour transform type");
@@ -804,7 +811,33 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
       f.mod_planes.push_back({ch.w, ch.h});
     }
     std::vector<ParsedFrame::ModOp> fwd;
+    size_t nb_meta = 0;
     for (auto& t : f.mod_transforms) {
+      if (t.id == 1) {
+        // Palette: num_c channels become one channel of indices, their colours travel in a meta channel (nb_colors x num_c) put
+        // first in the channel list; meta channels always live in the GlobalModular stream
+        REQUIRE(t.begin_c >= nb_meta && (size_t)t.begin_c + t.num_c <= cur.size(), "palette channel range");
+        const Chan first = cur[t.begin_c];
+        ParsedFrame::ModOp op;
+        op.kind = 3; op.type = (int32_t)t.nb_colors; op.nout = (int32_t)t.num_c;
+        for (uint32_t k = 0; k < t.num_c; k++) {
+          const Chan& ck = cur[t.begin_c + k];
+          REQUIRE(ck.w == first.w && ck.h == first.h && ck.hshift == first.hshift && ck.vshift == first.vshift, "palette on channels of different size");
+          op.out[k] = ck.plane;
+        }
+        Chan idx = first, pal;
+        idx.plane = (int32_t)f.mod_planes.size(); f.mod_planes.push_back({idx.w, idx.h});
+        pal.w = (int32_t)t.nb_colors; pal.h = (int32_t)t.num_c; pal.hshift = -1; pal.vshift = -1;
+        pal.plane = (int32_t)f.mod_planes.size(); f.mod_planes.push_back({pal.w, pal.h});
+        op.a = pal.plane; op.b = idx.plane;
+        fwd.push_back(op);
+        cur.erase(cur.begin() + t.begin_c, cur.begin() + t.begin_c + t.num_c);
+        cur.insert(cur.begin() + t.begin_c, idx);
+        cur.insert(cur.begin(), pal);
+        nb_meta++;
+        f.mod_has_palette = true;
+        continue;
+      }
       if (t.id == 0) {
         REQUIRE((size_t)t.begin_c + 3 <= cur.size(), "reversible colour transform out of range");
         const Chan &a = cur[t.begin_c], &b2 = cur[t.begin_c + 1], &c2 = cur[t.begin_c + 2];
@@ -815,13 +848,15 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
       f.mod_has_squeeze = true;
       std::vector<ParsedFrame::ModSqueeze> sq = t.squeezes;
       if (sq.empty()) {   // default parameters: chroma first, then alternate until no side exceeds 8
-        const int nb = (int)cur.size();
-        int w = cur[0].w, h = cur[0].h;
-        if (nb > 2 && cur[1].w == w && cur[1].h == h) {
-          sq.push_back({true, false, 1, 2});
-          sq.push_back({false, false, 1, 2});
+        const int nb = (int)(cur.size() - nb_meta);   // (meta channels - a palette - are left alone)
+        REQUIRE(nb > 0, "squeeze without channels");
+        const uint32_t m0 = (uint32_t)nb_meta;
+        int w = cur[m0].w, h = cur[m0].h;
+        if (nb > 2 && cur[m0 + 1].w == w && cur[m0 + 1].h == h) {
+          sq.push_back({true, false, m0 + 1, 2});
+          sq.push_back({false, false, m0 + 1, 2});
         }
-        ParsedFrame::ModSqueeze p{true, true, 0, (uint32_t)nb};
+        ParsedFrame::ModSqueeze p{true, true, m0, (uint32_t)nb};
         if (h > w && h > 8) { p.horizontal = false; sq.push_back(p); h = (h + 1) / 2; }
         while (w > 8 || h > 8) {
           if (w > 8) { p.horizontal = true; sq.push_back(p); w = (w + 1) / 2; }
@@ -830,6 +865,7 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
       }
       for (auto& q : sq) {
         REQUIRE(q.num_c > 0 && (size_t)q.begin_c + q.num_c <= cur.size(), "squeeze channel range");
+        REQUIRE(q.begin_c >= nb_meta, "squeeze of meta channels is not supported yet");
         const uint32_t end_c = q.begin_c + q.num_c - 1;
         const size_t offset = q.in_place ? end_c + 1 : cur.size();
         for (uint32_t c = q.begin_c; c <= end_c; c++) {
@@ -847,7 +883,7 @@ void ReadLfGlobal(Bits& r, ParsedFrame& f) {
     }
     f.mod_coded = cur;
     f.mod_ops.assign(fwd.rbegin(), fwd.rend());
-    uint32_t fg = 0;
+    uint32_t fg = (uint32_t)nb_meta;
     for (; fg < cur.size(); fg++) if (cur[fg].w > (int32_t)f.group_dim || cur[fg].h > (int32_t)f.group_dim) break;
     f.mod_first_group_channel = fg;
   }

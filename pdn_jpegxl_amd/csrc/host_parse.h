@@ -123,19 +123,22 @@ struct ParsedFrame {
   bool global_modular_has_channels = false;
   // Modular frames (encoding 1): the GlobalModular image header
   struct ModSqueeze { bool horizontal = false, in_place = false; uint32_t begin_c = 0, num_c = 0; };
-  struct ModTransform { uint32_t id = 0, begin_c = 0, rct_type = 0; std::vector<ModSqueeze> squeezes; };
-  std::vector<ModTransform> mod_transforms;   // RCT and Squeeze (Palette is rejected)
+  struct ModTransform { uint32_t id = 0, begin_c = 0, rct_type = 0, num_c = 0, nb_colors = 0, nb_deltas = 0, predictor = 0; std::vector<ModSqueeze> squeezes; };
+  std::vector<ModTransform> mod_transforms;   // RCT, Palette (plain: no delta entries) and Squeeze
   uint64_t mod_data_bits = 0;                 // codestream bit position of the GlobalModular channel data (stream 0)
   // Channel layout after the transforms (what the streams code) and the inverse operations in execution order.
   // Every channel instance owns a plane; planes 0 .. nch-1 are the image channels the inverse ends in.
   struct ModPlane { int32_t w = 0, h = 0; };
   struct ModChan { int32_t w = 0, h = 0, hshift = 0, vshift = 0, plane = 0; };
-  struct ModOp { int32_t kind = 0; int32_t a = 0, b = 0, c = 0, type = 0; };   // kind 0: RCT on planes a,b,c; 1 / 2: horizontal / vertical unsqueeze (avg a, residual b) -> plane c
+  // kind 0: RCT on planes a,b,c; 1 / 2: horizontal / vertical unsqueeze (avg a, residual b) -> plane c;
+  // 3: palette lookup: palette plane a (type colours wide, one row per output), index plane b -> planes out[0 .. nout)
+  struct ModOp { int32_t kind = 0; int32_t a = 0, b = 0, c = 0, type = 0; int32_t out[4] = {0, 0, 0, 0}; int32_t nout = 0; };
   std::vector<ModPlane> mod_planes;
   std::vector<ModChan> mod_coded;
   std::vector<ModOp> mod_ops;
   uint32_t mod_first_group_channel = 0;       // coded channels before this one live in the GlobalModular stream
   bool mod_has_squeeze = false;
+  bool mod_has_palette = false;
   bool single = false;                 // one TOC entry: all sections share one bit stream (frames that fit one group)
   uint64_t after_lf_global_bits = 0;   // codestream bit position right after the host-parsed part of LfGlobal
   uint64_t hf_start_bits = 0;          // single-section frames: bit position right after HfGlobal (set by the LF pre-pass)

@@ -22,6 +22,10 @@ void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
                       int lanes, int rb_width, int wp_lds, hipStream_t s);
 void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
+// inverse Palette: out[k][i] = palette[k * nb_colors + index[i]] for the w x h samples of the index channel; indices outside the
+// stored palette (implicit / delta colours) raise the image's error flag
+void LaunchModularPalette(const int32_t* palette, const int32_t* index, int32_t* const* out, int nout, int nb_colors, int w, int h, uint32_t* status,
+                          hipStream_t s);
 void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStream_t s);
 // src: w x h pixels of px_bytes each as stored; dst: the same image with EXIF orientation 2..8 applied (sides swapped for 5..8)
 void LaunchOrient(const uint8_t* src, uint8_t* dst, int w, int h, int px_bytes, int orientation, hipStream_t s);

@@ -102,3 +102,31 @@ def test_corrupt_lossless_stream_is_reported(oracle):
     data[len(data) // 2 + 1] ^= 0xAA
     with pytest.raises(api.JxlError):
         api.load_image(bytes(data))
+
+
+def _palette_image(w, h, ncol, nch, seed):
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, 256, (ncol, nch), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    idx = (xx // 7 + yy // 5 + (xx * yy) // 977) % ncol
+    return np.ascontiguousarray(cols[idx])
+
+
+@pytest.mark.parametrize("case", [(300, 200, 17, 4), (700, 530, 200, 3), (120, 90, 5, 1), (600, 300, 900, 4), (200, 140, 40, 2), (1030, 260, 300, 3)])
+@pytest.mark.parametrize("squeeze", [False, True])
+def test_palette_streams_decode_bit_exact(oracle, case, squeeze):
+    """Palette transform (images of few colours: one channel of indices + the colours in a meta channel of the global stream), alone
+    and under Squeeze; one-group and multi-group frames, 1 to 4 channels through one palette."""
+    w, h, ncol, nch = case
+    img = _palette_image(w, h, ncol, nch, 7 * ncol + nch)
+    data = oracle.encode(img, lossless=True, palette=True, lossless_squeeze=squeeze)
+    assert len(data) < len(oracle.encode(img, lossless=True, lossless_squeeze=squeeze))   # the transform was really used
+    assert (oracle.decode(data).pixels == img).all()
+    got = api.load_image(data)
+    assert got.pixels.shape == img.shape and (got.pixels == img).all()
+
+
+def test_palette_with_prefix_codes_and_lz77(oracle):
+    img = _palette_image(520, 300, 12, 4, 3)
+    data = oracle.encode(img, lossless=True, palette=True, prefix_codes=True, lz77=True)
+    assert (api.load_image(data).pixels == img).all()

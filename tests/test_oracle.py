@@ -236,3 +236,15 @@ def test_stream_coding_variants_decode_to_the_same_pixels(oracle, opts):
         assert np.abs(a.astype(int) - img.astype(int)).mean() < 6 and (a != b).any()
     else:
         assert (a == b).all()
+
+
+@pytest.mark.parametrize("nch", [1, 2, 3, 4])
+def test_palette_round_trip(oracle, nch):
+    rng = np.random.default_rng(nch)
+    cols = rng.integers(0, 256, (23, nch), dtype=np.uint8)
+    yy, xx = np.mgrid[0:190, 0:310]
+    img = np.ascontiguousarray(cols[(xx // 9 + yy // 4) % 23])
+    for squeeze in (False, True):
+        data = oracle.encode(img, lossless=True, palette=True, lossless_squeeze=squeeze)
+        assert (oracle.decode(data).pixels == img).all()
+        assert len(data) < len(oracle.encode(img, lossless=True, lossless_squeeze=squeeze))

@@ -1514,11 +1514,15 @@ __global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) 
       PredictWaveTiled<true>((const I4*)im.tree, 0, sid, plane, im.w, gw, gh, d.kind, d.value, out, im.w, (JXL_LDS int32_t*)s_carry,
                              (JXL_LDS int32_t*)s_tile, lane);
     } else {
+      // constant (e.g. fully opaque) or already final samples: row by row, no division per sample
       const bool cst = d.kind == kChanConst;
-      for (int i = lane; i < gw * gh; i += 64) {
-        const size_t o = (size_t)(i / gw) * im.w + (i % gw);
-        const int v = cst ? d.value : plane[o];
-        out[o] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+      const uint8_t cv = (uint8_t)(d.value < 0 ? 0 : (d.value > 255 ? 255 : d.value));
+      for (int y = 0; y < gh; y++) {
+        const size_t ro = (size_t)y * im.w;
+        for (int x = lane; x < gw; x += 64) {
+          const int v = cst ? 0 : plane[ro + x];
+          out[ro + x] = cst ? cv : (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
       }
     }
     return;

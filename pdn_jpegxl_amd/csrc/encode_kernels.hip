@@ -758,14 +758,16 @@ __device__ __forceinline__ bool LossyStream(const EncImage& im, int st, DevToken
 }
 // Reverse (state) passes: one wavefront per token stream - the only serial part of the entropy coder, so the two streams of an LF
 // group (196 k + 65 k tokens) and of a pass group run side by side instead of one after the other.
-__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_reverse_kernel(EncImage im) {
+// `which` = 0: the streams coded with the Modular code (LF coefficients, block metadata, alpha); 1: the HF coefficient streams.  Two
+// launches, because the Modular code is ready long before the (much larger) HF code: the host builds the latter while the longest
+// recurrence of the frame - the LF coefficients of an LF group - is already running.
+__global__ __launch_bounds__(64 * kSectionsPerWg) void enc_reverse_kernel(EncImage im, int which) {
   extern __shared__ __align__(16) uint8_t enc_smem[];
   size_t off;
   {
-    EncCodeDev lm, la;
-    off = StageEncCode(enc_smem, 0, im.mcode, &lm, true, threadIdx.x, blockDim.x);
-    off = StageEncCode(enc_smem, off, im.acode, &la, false, threadIdx.x, blockDim.x);
-    im.mcode = lm; im.acode = la;
+    EncCodeDev l;
+    if (which == 0) { off = StageEncCode(enc_smem, 0, im.mcode, &l, true, threadIdx.x, blockDim.x); im.mcode = l; }
+    else { off = StageEncCode(enc_smem, 0, im.acode, &l, false, threadIdx.x, blockDim.x); im.acode = l; }
     __syncthreads();
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -775,6 +777,7 @@ __global__ __launch_bounds__(64 * kSectionsPerWg) void enc_reverse_kernel(EncIma
   uint32_t n;
   bool modular;
   if (!LossyStream(im, st, &tok, &n, &modular)) return;
+  if (modular != (which == 0)) return;
   const uint32_t state = ReversePass(tok, n, modular ? im.mcode : im.acode, sc, lane);
   if (lane == 0) im.stream_state[st] = state;
 }
@@ -943,12 +946,14 @@ void LaunchEncTokens(const EncImage& im, hipStream_t s) {
 static size_t EncCodeLds(const EncCodeDev& c, bool with_rmap) {   // as StageEncCode carves it
   return 16 + (size_t)c.num_clusters * (kEncSyms * 4 + (with_rmap ? 8192 : 0)) + c.num_ctx;
 }
-void LaunchEncSections(const EncImage& im, hipStream_t s) {
-  // reverse passes: LDS = modular code with its slot map + HF code without + one scratch block per wavefront
-  const size_t lds = EncCodeLds(im.mcode, true) + EncCodeLds(im.acode, false) + 16 + kSectionsPerWg * sizeof(WaveScratch);
+void LaunchEncReverse(const EncImage& im, int which, hipStream_t s) {
+  // reverse passes: LDS = the code of this launch (the Modular one with its slot map) + one scratch block per wavefront
+  const size_t lds = (which == 0 ? EncCodeLds(im.mcode, true) : EncCodeLds(im.acode, false)) + 32 + kSectionsPerWg * sizeof(WaveScratch);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)enc_reverse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int nstreams = 2 * (im.nlf + im.ng);
-  hipLaunchKernelGGL(enc_reverse_kernel, dim3((unsigned)((nstreams + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im);
+  hipLaunchKernelGGL(enc_reverse_kernel, dim3((unsigned)((nstreams + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), lds, s, im, which);
+}
+void LaunchEncSections(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_sections_kernel, dim3((unsigned)((im.nlf + im.ng + kSectionsPerWg - 1) / kSectionsPerWg)), dim3(64 * kSectionsPerWg), 0, s, im);
   if (im.has_alpha && im.ng == 1) hipLaunchKernelGGL(enc_global_alpha_kernel, dim3(1), dim3(64), 0, s, im);
 }

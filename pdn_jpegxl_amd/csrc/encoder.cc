@@ -27,6 +27,7 @@ namespace jxlhip {
 void LaunchEncAnalyze(const EncImage& im, hipStream_t s);
 void LaunchEncFrontEnd(const EncImage& im, hipStream_t s);
 void LaunchEncTokens(const EncImage& im, hipStream_t s);
+void LaunchEncReverse(const EncImage& im, int which, hipStream_t s);
 void LaunchEncSections(const EncImage& im, hipStream_t s);
 void LaunchEncCompact(const EncImage& im, const uint64_t* dst_off, uint8_t* dst, int nsec, hipStream_t s);
 void LaunchEncLossless(const EncImage& im, int stage, hipStream_t s);
@@ -388,21 +389,40 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
     pinned[kLeafStrategy] = im.squares ? 0 : 1;  // ... and so is the strategy row while every block is an 8x8 DCT
     BuildAndWriteCode(hist_mod.data(), kNumEncLeaves, 8, pinned, lf_global, mcode);
   }
+  clk.Lap("host: tree + modular code");
+  // The Modular code is ready: start the recurrences of its streams (the LF coefficients of an LF group are the longest of the frame)
+  // on a stream of their own, and build the HF code meanwhile.
+  hipStream_t s_ans = nullptr, s_hf = nullptr;
+  ENC_HIP(hipStreamCreateWithFlags(&s_ans, hipStreamNonBlocking));
+  struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); } } } s_ans_guard{s_ans};
+  ENC_HIP(hipStreamCreateWithFlags(&s_hf, hipStreamNonBlocking));   // the HF streams' recurrences run beside the Modular ones
+  StreamGuard s_hf_guard{s_hf};
+  const int nsec = im.nlf + im.ng + 1;   // + the global alpha stream of single-group frames
+  im.mcode = UploadCode(A, mcode);
+  im.sec_cap = ((size_t)std::max(kLfTokCap + kMetaTokCap, kAcTokCap + kAlphaTokCap) * 6 + 256) & ~(size_t)15;
+  im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
+  im.sec_bits = A.Get<uint64_t>(nsec, true);
+  im.stream_state = A.Get<uint32_t>((size_t)2 * (im.nlf + im.ng) + 1, true);
+  ENC_HIP(hipDeviceSynchronize());   // tokens, histogram downloads and the clears above are done before the other stream starts
+  LaunchEncReverse(im, 0, s_ans);
   if (im.has_alpha) lf_global.Write(4, 3);   // global Modular image header: global tree, default predictor, no transforms
   hf_global.Bool(true);                      // default dequantisation matrices
   hf_global.Write(im.ng <= 1 ? 0 : 32 - __builtin_clz((unsigned)(im.ng - 1)), 0);   // one HF preset
   hf_global.U32(WV(0x5F), WV(0x13), WV(0), WB(kNumOrders), 0);                       // natural coefficient orders
   BuildAndWriteCode(hist_ac.data(), kAcContexts, 64, {}, hf_global, acode);
-  clk.Lap("host: tree + codes");
-  // ---- 6. ANS coding of every section on the GPU
-  im.mcode = UploadCode(A, mcode);
+  clk.Lap("host: HF code (overlaps the LF recurrences)");
+  // ---- 6. ANS coding of every section on the GPU (the Modular streams' recurrences have been running since their code was built)
   im.acode = UploadCode(A, acode);
-  const int nsec = im.nlf + im.ng + 1;   // + the global alpha stream of single-group frames
-  im.sec_cap = ((size_t)std::max(kLfTokCap + kMetaTokCap, kAcTokCap + kAlphaTokCap) * 6 + 256) & ~(size_t)15;
-  im.sec_bytes = A.Get<uint8_t>((size_t)nsec * im.sec_cap);
-  im.sec_bits = A.Get<uint64_t>(nsec, true);
-  im.stream_state = A.Get<uint32_t>((size_t)2 * (im.nlf + im.ng) + 1, true);
-  LaunchEncSections(im, s);
+  LaunchEncReverse(im, 1, s_hf);
+  {
+    hipEvent_t hf_done;
+    ENC_HIP(hipEventCreateWithFlags(&hf_done, hipEventDisableTiming));
+    ENC_HIP(hipEventRecord(hf_done, s_hf));
+    ENC_HIP(hipStreamWaitEvent(s_ans, hf_done, 0));
+    LaunchEncSections(im, s_ans);   // bit layout of every section: needs the states of both kinds of stream
+    ENC_HIP(hipStreamSynchronize(s_ans));
+    (void)hipEventDestroy(hf_done);
+  }
   clk.Lap("ans sections");
   std::vector<uint64_t> sec_bits(nsec);
   ENC_HIP(hipMemcpy(sec_bits.data(), im.sec_bits, sec_bits.size() * 8, hipMemcpyDeviceToHost));

@@ -45,10 +45,11 @@ struct EncImage {
   int32_t* alpha_px;        // w*h
   int32_t* lfq[3];          // w8*h8 quantised LF (X, Y, B)
   int32_t* rawq;            // w8*h8 raw quant field (1..256)
-  // varblocks: 8x8, 16x16 or 32x32 DCTs (the squares the block kernel chooses between; `squares` = 0: 8x8 only, the fast effort)
+  // varblocks: `squares` = 0: 8x8 DCTs only (the fast effort); 1: 8x8 / 16x16 / 32x32; 2: also 64x64 and the rectangular
+  // 16x8 ... 64x32 shapes (the default effort)
   int32_t squares, pad1;
   float* act;               // w8*h8 activity of Y per cell (standard deviation)
-  uint8_t* strat;           // w8*h8: strategy of the varblock covering the cell (0 DCT8, 4 DCT16X16, 5 DCT32X32) | 0x80 on its first cell
+  uint8_t* strat;           // w8*h8: strategy code of the varblock covering the cell | 0x80 on its first cell
   int32_t* qs[3];           // w8*h8*64 quantised coefficients: scan position k of a varblock at its covered cell (k >> 6, row-major) * 64 + (k & 63)
   uint8_t* nz[3];           // per cell: the non-zero context value of the varblock covering it, (count + covered - 1) >> log2(covered)
   uint16_t* nzc[3];         // per first cell: number of non-zero HF coefficients of the varblock
@@ -60,14 +61,15 @@ struct EncImage {
   float x_dm, b_dm;         // 0.8 ^ (x_qm_scale - 2), 0.8 ^ (b_qm_scale - 2)
   float qbias1, qbias3;     // quantisation bias of |q| == 1 (Y) and the 1/q term
   float gab_w[3][3];
-  // per transform size N = 8, 16, 32 (index 0..2): inverse natural order (stored index kx * N + ky -> scan position), 3 * N * N
-  // dequantisation multipliers (stored layout), the basis B[k * N + n] and the same divided by N
-  const uint16_t* scan_of[3];
-  const float* dq[3];
-  const float* basis[3];
-  const float* basis_div[3];
-  const float* bsmall[3];   // c x c basis for c = 1, 2, 4 (LF values of a varblock from its lowest c x c coefficients)
-  float rs[3][16];          // resample scale of coefficient (ky, kx) of the lowest c x c, [ky * c + kx], c = 1, 2, 4
+  // per order bucket (13): inverse natural order (stored index -> scan position); per quant table (17): 3 * n dequantisation
+  // multipliers in the stored layout; per transform length N = 8, 16, 32, 64 (index 0..3): the basis B[k * N + n] and the same divided
+  // by N; per c = 1, 2, 4, 8: the c x c basis (LF values of a varblock from its lowest coefficients) and the resample scales
+  const uint16_t* scan_of[13];
+  const float* dq[17];
+  const float* basis[4];
+  const float* basis_div[4];
+  const float* bsmall[4];
+  const float* rs;          // [(lcy * 4 + lcx) * 64 + ky * 8 + kx]: scale of coefficient (ky, kx) of the lowest cy x cx
   // tokens
   DevToken* tok_lf;         // [nlf][kLfTokCap]
   DevToken* tok_meta;       // [nlf][kMetaTokCap]

@@ -131,184 +131,195 @@ __global__ void enc_activity_kernel(EncImage im) {
   }
 }
 
-// One thread per aligned 32x32 region (4 x 4 cells): a 32x32 DCT if the region is inside the frame and flat, else per aligned 16x16
-// quadrant a 16x16 DCT under the same test with its own threshold, else 8x8 DCTs - the raster-greedy choice over aligned squares.
-// The quant field of a varblock follows its mean activity (finer steps in flat areas).
+// Strategy tables (the shapes this encoder uses): cells covered across / down (log2), order bucket, quantisation table.
+__device__ const uint8_t e_lcx[27] = {0, 0, 0, 0, 1, 2, 0, 1, 0, 2, 1, 2, 0, 0, 0, 0, 0, 0, 3, 2, 3, 4, 3, 4, 5, 4, 5};
+__device__ const uint8_t e_lcy[27] = {0, 0, 0, 0, 1, 2, 1, 0, 2, 0, 2, 1, 0, 0, 0, 0, 0, 0, 3, 3, 2, 4, 4, 3, 5, 5, 4};
+__device__ const uint8_t e_bucket[27] = {0, 1, 1, 1, 2, 3, 4, 4, 5, 5, 6, 6, 1, 1, 1, 1, 1, 1, 7, 8, 8, 9, 10, 10, 11, 12, 12};
+__device__ const uint8_t e_qtable[27] = {0, 1, 2, 3, 4, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 10, 10, 11, 12, 12, 13, 14, 14, 15, 16, 16};
+
+// One thread per aligned 64x64 region (8 x 8 cells).  The choice is the raster-greedy one: cells in raster order, at every free cell the
+// largest shape of the list that is aligned to its own size there, lies inside the frame, covers only free cells and whose cells' maximum
+// activity stays under the shape's threshold.  Shapes of at most 64 points aligned to their size never leave their aligned 64x64
+// region, so the regions decide independently.  The quant field of a varblock follows its mean activity (finer steps in flat areas).
 __global__ void enc_strategy_kernel(EncImage im) {
-  const int rw = (im.w8 + 3) / 4, rh = (im.h8 + 3) / 4;
+  const int rw = (im.w8 + 7) / 8, rh = (im.h8 + 7) / 8;
+  // strategy code, threshold; `squares` == 1 keeps the square shapes of at most 32 points
+  const int kShape[9] = {18, 19, 20, 5, 10, 11, 4, 6, 7};   // 64x64, 64x32, 32x64, 32x32, 32x16, 16x32, 16x16, 16x8, 8x16
+  const float kThr[9] = {0.0035f, 0.0045f, 0.0045f, 0.007f, 0.009f, 0.009f, 0.016f, 0.024f, 0.024f};
   for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < rw * rh; r += gridDim.x * blockDim.x) {
-    const int bx0 = (r % rw) * 4, by0 = (r / rw) * 4;
-    auto act = [&](int ix, int iy) { return im.act[(size_t)(by0 + iy) * im.w8 + bx0 + ix]; };
-    auto place = [&](int ix, int iy, int c, int strategy) {   // c x c cells from (ix, iy)
-      double a = 0;
-      for (int y = 0; y < c; y++) for (int x = 0; x < c; x++) a += act(ix + x, iy + y);
-      a /= c * c;
-      const double mod = 0.7 + 0.8 / (1.0 + a / 0.012);
-      int q = (int)rint(16.0 * mod);
-      q = max(1, min(256, q));
-      for (int y = 0; y < c; y++)
-        for (int x = 0; x < c; x++) {
-          const size_t cell = (size_t)(by0 + iy + y) * im.w8 + bx0 + ix + x;
-          im.strat[cell] = (uint8_t)(strategy | ((x | y) == 0 ? 0x80 : 0));
-          im.rawq[cell] = q;
-        }
-    };
-    const bool whole = im.squares && bx0 + 4 <= im.w8 && by0 + 4 <= im.h8;
-    float mx = 0.f;
-    if (whole) for (int y = 0; y < 4; y++) for (int x = 0; x < 4; x++) mx = fmaxf(mx, act(x, y));
-    if (whole && mx < 0.007f) { place(0, 0, 4, 5); continue; }
-    for (int qy = 0; qy < 4; qy += 2)
-      for (int qx = 0; qx < 4; qx += 2) {
-        const bool inside = bx0 + qx + 2 <= im.w8 && by0 + qy + 2 <= im.h8;
-        if (im.squares && inside && fmaxf(fmaxf(act(qx, qy), act(qx + 1, qy)), fmaxf(act(qx, qy + 1), act(qx + 1, qy + 1))) < 0.016f) { place(qx, qy, 2, 4); continue; }
-        for (int y = 0; y < 2; y++)
-          for (int x = 0; x < 2; x++)
-            if (bx0 + qx + x < im.w8 && by0 + qy + y < im.h8) place(qx + x, qy + y, 1, 0);
+    const int bx0 = (r % rw) * 8, by0 = (r / rw) * 8;
+    uint64_t occ = 0;   // cells of the region already covered (bit iy * 8 + ix)
+    for (int iy = 0; iy < 8 && by0 + iy < im.h8; iy++)
+      for (int ix = 0; ix < 8 && bx0 + ix < im.w8; ix++) {
+        if (occ >> (iy * 8 + ix) & 1) continue;
+        int s = 0;
+        if (im.squares)
+          for (int t = 0; t < 9; t++) {
+            const int cand = kShape[t];
+            if (im.squares == 1 && cand != 5 && cand != 4) continue;
+            const int cx = 1 << e_lcx[cand], cy = 1 << e_lcy[cand];
+            if ((ix & (cx - 1)) || (iy & (cy - 1)) || bx0 + ix + cx > im.w8 || by0 + iy + cy > im.h8) continue;
+            const uint64_t rowm = ((1ull << cx) - 1) << ix;
+            uint64_t m = 0;
+            for (int y = 0; y < cy; y++) m |= rowm << ((iy + y) * 8);
+            if (m & occ) continue;
+            float mx = 0.f;
+            for (int y = 0; y < cy; y++)
+              for (int x = 0; x < cx; x++) mx = fmaxf(mx, im.act[(size_t)(by0 + iy + y) * im.w8 + bx0 + ix + x]);
+            if (mx < kThr[t]) { s = cand; break; }
+          }
+        const int cx = 1 << e_lcx[s], cy = 1 << e_lcy[s];
+        double a = 0;
+        for (int y = 0; y < cy; y++)
+          for (int x = 0; x < cx; x++) a += im.act[(size_t)(by0 + iy + y) * im.w8 + bx0 + ix + x];
+        a /= cx * cy;
+        const double mod = 0.7 + 0.8 / (1.0 + a / 0.012);
+        int q = (int)rint(16.0 * mod);
+        q = max(1, min(256, q));
+        for (int y = 0; y < cy; y++)
+          for (int x = 0; x < cx; x++) {
+            const size_t cell = (size_t)(by0 + iy + y) * im.w8 + bx0 + ix + x;
+            im.strat[cell] = (uint8_t)(s | ((x | y) == 0 ? 0x80 : 0));
+            im.rawq[cell] = q;
+            occ |= 1ull << ((iy + y) * 8 + ix + x);
+          }
       }
   }
 }
 
-// One workgroup per 32x32 region: every sample position of the region belongs to exactly one varblock, so both DCT passes run over
-// all 1024 positions at once (a thread's loop length is its varblock's side), through LDS.  Then per coefficient: its scan position,
-// quantisation (Y first; X; B after chroma from luma with the dequantised Y), non-zero statistics; and per cell the quantised LF
-// from the varblock's lowest c x c coefficients.
+// One workgroup per 64x64 region, one channel at a time (Y first: X needs nothing from it, B the dequantised Y for chroma from luma):
+// every sample position of the region belongs to exactly one varblock, so both DCT passes run over all 4096 positions at once (a
+// thread's loop length is its varblock's height / width), through LDS.  Then per coefficient: its scan position, quantisation,
+// non-zero statistics; and per cell the quantised LF from the varblock's lowest cy x cx coefficients.
 __global__ __launch_bounds__(256) void enc_varblock_kernel(EncImage im) {
-  constexpr int P = 33;
-  __shared__ float s_a[3][32 * P];   // pixels, later the coefficients
-  __shared__ float s_t[3][32 * P];   // after the vertical pass
-  __shared__ uint8_t s_strat[16];
-  __shared__ uint32_t s_nz[16][3], s_last[16][3];
-  const int rw = (im.w8 + 3) / 4;
-  const int bx0 = (blockIdx.x % rw) * 4, by0 = (blockIdx.x / rw) * 4;
+  constexpr int P = 65;
+  __shared__ float s_a[64 * P];    // pixels, later the coefficients of the channel
+  __shared__ float s_t[64 * P];    // after the vertical pass
+  __shared__ float s_yd[64 * P];   // dequantised Y coefficients (chroma from luma of B)
+  __shared__ uint8_t s_strat[64];
+  __shared__ uint32_t s_nz[64], s_last[64];
+  __shared__ float s_fy[64];       // dequantised LF of Y per cell
+  const int rw = (im.w8 + 7) / 8;
+  const int bx0 = (blockIdx.x % rw) * 8, by0 = (blockIdx.x / rw) * 8;
   const int tid = threadIdx.x;
-  if (tid < 16) {
-    const int ix = tid & 3, iy = tid >> 2;
+  if (tid < 64) {
+    const int ix = tid & 7, iy = tid >> 3;
     s_strat[tid] = (bx0 + ix < im.w8 && by0 + iy < im.h8) ? im.strat[(size_t)(by0 + iy) * im.w8 + bx0 + ix] : 0xFF;   // 0xFF: outside the frame
-    for (int c = 0; c < 3; c++) { s_nz[tid][c] = 0; s_last[tid][c] = 0; }
-  }
-  for (int i = tid; i < 1024; i += 256) {
-    const int y = i >> 5, x = i & 31;
-    const bool in = bx0 * 8 + x < im.wp && by0 * 8 + y < im.hp;
-    for (int c = 0; c < 3; c++) s_a[c][y * P + x] = in ? im.pad[c][(size_t)(by0 * 8 + y) * im.wp + bx0 * 8 + x] : 0.f;
   }
   __syncthreads();
-  // geometry of the varblock that holds region position (y, x): side N (8 << lc), origin (oy, ox), all from the cell's strategy
-  auto geom = [&](int y, int x, int* lc, int* oy, int* ox) -> bool {
-    const uint32_t st = s_strat[(y >> 3) * 4 + (x >> 3)];
+  // geometry of the varblock that holds region position (y, x)
+  auto geom = [&](int y, int x, int* s, int* oy, int* ox) -> bool {
+    const uint32_t st = s_strat[(y >> 3) * 8 + (x >> 3)];
     if (st == 0xFF) return false;
-    const int l = (st & 0x7F) == 5 ? 2 : ((st & 0x7F) == 4 ? 1 : 0);
-    *lc = l;
-    *oy = y & ~((8 << l) - 1);
-    *ox = x & ~((8 << l) - 1);
+    const int sc = (int)(st & 0x7F);
+    *s = sc;
+    *oy = y & ~((8 << e_lcy[sc]) - 1);
+    *ox = x & ~((8 << e_lcx[sc]) - 1);
     return true;
   };
-  // vertical: t[oy + ky][x] = sum_y px[oy + y][x] * (B[ky][y] / N)
-  for (int i = tid; i < 1024; i += 256) {
-    const int y = i >> 5, x = i & 31;
-    int lc, oy, ox;
-    if (!geom(y, x, &lc, &oy, &ox)) continue;
-    const int N = 8 << lc, ky = y - oy;
-    const float* b = im.basis_div[lc] + ky * N;
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < N; k++) {
-      const float bv = b[k];
-      for (int c = 0; c < 3; c++) acc[c] += bv * s_a[c][(oy + k) * P + x];
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = ci == 0 ? 1 : (ci == 1 ? 0 : 2);
+    if (tid < 64) { s_nz[tid] = 0; s_last[tid] = 0; }
+    for (int i = tid; i < 4096; i += 256) {
+      const int y = i >> 6, x = i & 63;
+      const bool in = bx0 * 8 + x < im.wp && by0 * 8 + y < im.hp;
+      s_a[y * P + x] = in ? im.pad[c][(size_t)(by0 * 8 + y) * im.wp + bx0 * 8 + x] : 0.f;
     }
-    for (int c = 0; c < 3; c++) s_t[c][y * P + x] = acc[c];
-  }
-  __syncthreads();
-  // horizontal: coef[ky][kx] = (sum_x t[ky][ox + x] * B[kx][x]) / N ; kept in registers until every thread has read its inputs
-  float coef[4][3];
-  for (int j = 0; j < 4; j++) {
-    const int i = tid + j * 256, y = i >> 5, x = i & 31;
-    int lc, oy, ox;
-    coef[j][0] = coef[j][1] = coef[j][2] = 0.f;
-    if (!geom(y, x, &lc, &oy, &ox)) continue;
-    const int N = 8 << lc, kx = x - ox;
-    const float* b = im.basis[lc] + kx * N;
-    float acc[3] = {0.f, 0.f, 0.f};
-    for (int k = 0; k < N; k++) {
-      const float bv = b[k];
-      for (int c = 0; c < 3; c++) acc[c] += s_t[c][y * P + ox + k] * bv;
+    __syncthreads();
+    // vertical: t[oy + ky][x] = sum_y px[oy + y][x] * (B_R[ky][y] / R)
+    for (int i = tid; i < 4096; i += 256) {
+      const int y = i >> 6, x = i & 63;
+      int s, oy, ox;
+      if (!geom(y, x, &s, &oy, &ox)) continue;
+      const int lr = e_lcy[s], R = 8 << lr, ky = y - oy;
+      const float* b = im.basis_div[lr] + ky * R;
+      float acc = 0.f;
+      for (int k = 0; k < R; k++) acc += b[k] * s_a[(oy + k) * P + x];
+      s_t[y * P + x] = acc;
     }
-    for (int c = 0; c < 3; c++) coef[j][c] = acc[c] / (float)N;
-  }
-  __syncthreads();
-  for (int j = 0; j < 4; j++) {
-    const int i = tid + j * 256, y = i >> 5, x = i & 31;
-    for (int c = 0; c < 3; c++) s_a[c][y * P + x] = coef[j][c];
-  }
-  __syncthreads();
-  // quantisation of the HF coefficients
-  for (int j = 0; j < 4; j++) {
-    const int i = tid + j * 256, y = i >> 5, x = i & 31;
-    int lc, oy, ox;
-    if (!geom(y, x, &lc, &oy, &ox)) continue;
-    const int N = 8 << lc, ky = y - oy, kx = x - ox, cc = 1 << lc;
-    const uint32_t p = (uint32_t)(kx * N + ky);          // stored (transposed) layout of a square DCT
-    const uint32_t k = im.scan_of[lc][p];
-    const int fcell = (oy >> 3) * 4 + (ox >> 3);         // first cell of the varblock, within the region
-    const size_t first = (size_t)(by0 + (oy >> 3)) * im.w8 + bx0 + (ox >> 3);
-    const float scale = im.inv_gs / (float)im.rawq[first];
-    const float dqs[3] = {scale * im.x_dm, scale, scale * im.b_dm};
-    int32_t qi[3] = {0, 0, 0};
-    if (!(ky < cc && kx < cc)) {   // the lowest c x c coefficients travel with the LF image
-      const float* dq = im.dq[lc];
-      const float wy = dq[N * N + p];
-      const float vy = coef[j][1] / (dqs[1] * wy);
-      qi[1] = fabsf(vy) < 0.6f ? 0 : (int32_t)rintf(vy);
-      const float adj = qi[1] == 0 ? 0.f : (abs(qi[1]) == 1 ? (qi[1] > 0 ? im.qbias1 : -im.qbias1) : (float)qi[1] - im.qbias3 / (float)qi[1]);
-      const float yd = adj * dqs[1] * wy;
-      const float vx = coef[j][0] / (dqs[0] * dq[p]);
-      qi[0] = fabsf(vx) < 0.6f ? 0 : (int32_t)rintf(vx);
-      const float vb = (coef[j][2] - yd) / (dqs[2] * dq[2 * N * N + p]);
-      qi[2] = fabsf(vb) < 0.6f ? 0 : (int32_t)rintf(vb);
+    __syncthreads();
+    // horizontal: coef[ky][kx] = (sum_x t[ky][ox + x] * B_C[kx][x]) / C
+    for (int i = tid; i < 4096; i += 256) {
+      const int y = i >> 6, x = i & 63;
+      int s, oy, ox;
+      if (!geom(y, x, &s, &oy, &ox)) continue;
+      const int lc = e_lcx[s], C = 8 << lc, kx = x - ox;
+      const float* b = im.basis[lc] + kx * C;
+      float acc = 0.f;
+      for (int k = 0; k < C; k++) acc += s_t[y * P + ox + k] * b[k];
+      s_a[y * P + x] = acc / (float)C;   // every thread reads s_t and writes its own s_a element: no hazard
     }
-    // scan position k lives in the slot of the varblock's covered cell number k >> 6 (row-major)
-    const uint32_t cj = k >> 6;
-    const size_t slot = (first + (size_t)(cj >> lc) * im.w8 + (cj & (cc - 1))) * 64 + (k & 63);
-    for (int c = 0; c < 3; c++) {
-      im.qs[c][slot] = qi[c];
-      if (qi[c]) { atomicAdd(&s_nz[fcell][c], 1u); atomicMax(&s_last[fcell][c], k); }
-    }
-  }
-  __syncthreads();
-  // per cell: non-zero context value of its varblock, LF from the lowest c x c coefficients; per first cell: counts
-  if (tid < 16) {
-    const int ix = tid & 3, iy = tid >> 2;
-    const uint32_t st = s_strat[tid];
-    if (st != 0xFF) {
-      int lc, oy, ox;
-      geom(iy * 8, ix * 8, &lc, &oy, &ox);
-      const int cc = 1 << lc, fcell = (oy >> 3) * 4 + (ox >> 3), cy = iy - (oy >> 3), cx = ix - (ox >> 3);
-      const size_t cell = (size_t)(by0 + iy) * im.w8 + bx0 + ix;
-      float lf[3];
-      for (int c = 0; c < 3; c++) {
-        // IDCT of the c x c lowest coefficients, undoing the resampling scale
-        const float* B = im.bsmall[lc];
-        float out = 0.f;
-        // horizontal then vertical, as the reference order of summation (tmp[ky][x] over kx, then over ky)
-        for (int ky = 0; ky < cc; ky++) {
-          float t = 0.f;
-          for (int kx = 0; kx < cc; kx++) {
-            const float v = s_a[c][(oy + ky) * P + ox + kx] / im.rs[lc][ky * cc + kx];
-            t += v * B[kx * cc + cx];
-          }
-          out += B[ky * cc + cy] * t;
+    __syncthreads();
+    // quantisation of the HF coefficients
+    for (int i = tid; i < 4096; i += 256) {
+      const int y = i >> 6, x = i & 63;
+      int s, oy, ox;
+      if (!geom(y, x, &s, &oy, &ox)) continue;
+      const int lcx = e_lcx[s], lcy = e_lcy[s], cx = 1 << lcx, cy = 1 << lcy, R = 8 << lcy, C = 8 << lcx;
+      const int ky = y - oy, kx = x - ox;
+      // stored layout: the longer side runs along a row (squares: transposed)
+      const uint32_t p = R >= C ? (uint32_t)(kx * R + ky) : (uint32_t)(ky * C + kx);
+      const uint32_t k = im.scan_of[e_bucket[s]][p];
+      const int fcell = (oy >> 3) * 8 + (ox >> 3);         // first cell of the varblock, within the region
+      const size_t first = (size_t)(by0 + (oy >> 3)) * im.w8 + bx0 + (ox >> 3);
+      const float scale = im.inv_gs / (float)im.rawq[first];
+      const float dqs = c == 1 ? scale : (c == 0 ? scale * im.x_dm : scale * im.b_dm);
+      const float coef = s_a[y * P + x];
+      int32_t qi = 0;
+      if (!(ky < cy && kx < cx)) {   // the lowest cy x cx coefficients travel with the LF image
+        const float w = im.dq[e_qtable[s]][(size_t)c * R * C + p];
+        const float target = c == 2 ? coef - s_yd[y * P + x] : coef;
+        const float v = target / (dqs * w);
+        qi = fabsf(v) < 0.6f ? 0 : (int32_t)rintf(v);
+        if (c == 1) {
+          const float adj = qi == 0 ? 0.f : (abs(qi) == 1 ? (qi > 0 ? im.qbias1 : -im.qbias1) : (float)qi - im.qbias3 / (float)qi);
+          s_yd[y * P + x] = adj * dqs * w;
         }
-        lf[c] = out;
+      } else if (c == 1) {
+        s_yd[y * P + x] = 0.f;
       }
-      const int32_t qy = (int32_t)rintf(lf[1] * im.inv_mul_lf[1]);
-      const float fy = (float)qy * im.mul_lf_y;
-      im.lfq[1][cell] = qy;
-      im.lfq[0][cell] = (int32_t)rintf(lf[0] * im.inv_mul_lf[0]);
-      im.lfq[2][cell] = (int32_t)rintf((lf[2] - fy) * im.inv_mul_lf[2]);
-      for (int c = 0; c < 3; c++) {
-        const uint32_t n = s_nz[fcell][c];
-        im.nz[c][cell] = (uint8_t)((n + (uint32_t)(cc * cc) - 1) >> (2 * lc));
-        if (st & 0x80) { im.nzc[c][cell] = (uint16_t)n; im.last[c][cell] = (uint16_t)s_last[fcell][c]; }
+      // scan position k lives in the slot of the varblock's covered cell number k >> 6 (row-major over cy rows of cx cells)
+      const uint32_t cj = k >> 6;
+      const size_t slot = (first + (size_t)(cj >> lcx) * im.w8 + (cj & (cx - 1))) * 64 + (k & 63);
+      im.qs[c][slot] = qi;
+      if (qi) { atomicAdd(&s_nz[fcell], 1u); atomicMax(&s_last[fcell], k); }
+    }
+    __syncthreads();
+    // per cell: non-zero context value of its varblock, LF from the lowest cy x cx coefficients; per first cell: counts
+    if (tid < 64) {
+      const int ix = tid & 7, iy = tid >> 3;
+      const uint32_t st = s_strat[tid];
+      if (st != 0xFF) {
+        int s, oy, ox;
+        geom(iy * 8, ix * 8, &s, &oy, &ox);
+        const int lcx = e_lcx[s], lcy = e_lcy[s], cx = 1 << lcx, cy = 1 << lcy;
+        const int fcell = (oy >> 3) * 8 + (ox >> 3), py = iy - (oy >> 3), px = ix - (ox >> 3);
+        const size_t cell = (size_t)(by0 + iy) * im.w8 + bx0 + ix;
+        // IDCT of the cy x cx lowest coefficients, undoing the resampling scale: horizontal then vertical
+        const float* Bx = im.bsmall[lcx];
+        const float* By = im.bsmall[lcy];
+        const float* rs = im.rs + (lcy * 4 + lcx) * 64;
+        float lf = 0.f;
+        for (int ky = 0; ky < cy; ky++) {
+          float t = 0.f;
+          for (int kx = 0; kx < cx; kx++) t += (s_a[(oy + ky) * P + ox + kx] / rs[ky * 8 + kx]) * Bx[kx * cx + px];
+          lf += By[ky * cy + py] * t;
+        }
+        if (c == 1) {
+          const int32_t qy = (int32_t)rintf(lf * im.inv_mul_lf[1]);
+          s_fy[tid] = (float)qy * im.mul_lf_y;
+          im.lfq[1][cell] = qy;
+        } else if (c == 0) {
+          im.lfq[0][cell] = (int32_t)rintf(lf * im.inv_mul_lf[0]);
+        } else {
+          im.lfq[2][cell] = (int32_t)rintf((lf - s_fy[tid]) * im.inv_mul_lf[2]);
+        }
+        const uint32_t n = s_nz[fcell];
+        im.nz[c][cell] = (uint8_t)((n + (uint32_t)(cx * cy) - 1) >> (lcx + lcy));
+        if (st & 0x80) { im.nzc[c][cell] = (uint16_t)n; im.last[c][cell] = (uint16_t)s_last[fcell]; }
       }
     }
+    __syncthreads();
   }
 }
 
@@ -475,7 +486,7 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
       const size_t cell = (size_t)(by0 + blk / bw) * im.w8 + bx0 + blk % bw;
       const uint32_t st = im.strat[cell];
       if (st & 0x80) {
-        const uint32_t lc = (st & 0x7F) == 5 ? 2u : ((st & 0x7F) == 4 ? 1u : 0u), covered = 1u << (2 * lc);
+        const uint32_t covered = 1u << (e_lcx[st & 0x7F] + e_lcy[st & 0x7F]);
         cnt = 1u + (im.nzc[c][cell] ? (uint32_t)im.last[c][cell] + 1u - covered : 0u);
       }
     }
@@ -503,15 +514,16 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
     const size_t cell = (size_t)(by0 + by) * im.w8 + bx0 + bx;
     const uint32_t st = im.strat[cell];
     if (!(st & 0x80)) continue;
-    const uint32_t lc = (st & 0x7F) == 5 ? 2u : ((st & 0x7F) == 4 ? 1u : 0u), cc = 1u << lc, log2c = 2 * lc, covered = 1u << log2c, size = covered << 6;
+    const uint32_t sc = st & 0x7F, lcx = e_lcx[sc], cc = 1u << lcx, log2c = lcx + e_lcy[sc], covered = 1u << log2c, size = covered << 6;
     const uint8_t* nzp = im.nz[c];
     const uint32_t nzeros0 = im.nzc[c][cell];
     uint32_t predicted;
     if (bx == 0) predicted = by == 0 ? 32u : (uint32_t)nzp[cell - im.w8];
     else if (by == 0) predicted = nzp[cell - 1];
     else predicted = ((uint32_t)nzp[cell - im.w8] + nzp[cell - 1] + 1) >> 1;
-    // default block-context map: Y -> 0 (8x8) / 2 (16x16, 32x32); X and B -> 7 / 9
-    const uint32_t block_ctx = (c == 1 ? 0u : 7u) + (lc ? 2u : 0u);
+    // default block-context map by order bucket: one row for Y, one shared by X and B
+    const uint8_t kCtxY[13] = {0, 1, 2, 2, 3, 3, 4, 5, 6, 6, 6, 6, 6}, kCtxXB[13] = {7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 14, 14, 14};
+    const uint32_t block_ctx = c == 1 ? kCtxY[e_bucket[sc]] : kCtxXB[e_bucket[sc]];
     uint32_t nzc = predicted >= 64 ? 64 : predicted;
     nzc = nzc < 8 ? nzc : 4 + nzc / 2;
     DevToken t;
@@ -527,7 +539,7 @@ __global__ __launch_bounds__(256) void enc_ac_tokens_kernel(EncImage im) {
     const uint32_t lastk = im.last[c][cell];
     for (uint32_t kk = covered; kk <= lastk; kk++) {
       const uint32_t cj = kk >> 6;
-      const int32_t q = im.qs[c][(cell + (size_t)(cj >> lc) * im.w8 + (cj & (cc - 1))) * 64 + (kk & 63)];
+      const int32_t q = im.qs[c][(cell + (size_t)(cj >> lcx) * im.w8 + (cj & (cc - 1))) * 64 + (kk & 63)];
       const uint32_t ks = kk >> log2c;
       const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 15 + ((ks - 16) >> 1) : 23 + ((ks - 32) >> 2));
       t.ctx = histo + ((uint32_t)e_nnz_ctx[(nzeros + covered - 1) >> log2c] + fctx) * 2 + prev;
@@ -933,7 +945,7 @@ void LaunchEncFrontEnd(const EncImage& im, hipStream_t s) {
   hipLaunchKernelGGL(enc_xyb_kernel, dim3(GridFor((size_t)im.w * im.h)), dim3(256), 0, s, im);
   hipLaunchKernelGGL(enc_sharpen_pad_kernel, dim3(GridFor((size_t)im.wp * im.hp)), dim3(256), 0, s, im);
   hipLaunchKernelGGL(enc_activity_kernel, dim3(GridFor((size_t)im.w8 * im.h8)), dim3(256), 0, s, im);
-  const unsigned regions = (unsigned)(((im.w8 + 3) / 4) * ((im.h8 + 3) / 4));
+  const unsigned regions = (unsigned)(((im.w8 + 7) / 8) * ((im.h8 + 7) / 8));
   hipLaunchKernelGGL(enc_strategy_kernel, dim3(GridFor(regions)), dim3(256), 0, s, im);
   hipLaunchKernelGGL(enc_varblock_kernel, dim3(regions), dim3(256), 0, s, im);
 }

@@ -309,18 +309,23 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
     for (int c = 0; c < 3; c++) { im.gab_w[c][0] = 1.0f / div; im.gab_w[c][1] = w1 / div; im.gab_w[c][2] = w2 / div; }
   }
   // effort (JxlEncoderTypes.h:29, passed to the encoder library as its effort setting, Encoder/JxlEncoder.cpp:319-326): the library's
-  // fast settings (1..4) keep every block an 8x8 DCT; from 5 up (7 is the host's default) flat regions get 16x16 / 32x32 DCTs
-  im.squares = opt->effort >= 5 ? 1 : 0;
+  // fast settings (1..4) keep every block an 8x8 DCT; 5 and 6 add 16x16 / 32x32 DCTs on flat regions; from 7 (the host's default) the
+  // 64x64 and the rectangular 16x8 ... 64x32 shapes join
+  im.squares = opt->effort >= 7 ? 2 : (opt->effort >= 5 ? 1 : 0);
   const StaticTables& st = GetStaticTables();
   {
-    const int order_bucket[3] = {0, 2, 3}, quant_table[3] = {0, 4, 5};   // DCT8, DCT16X16, DCT32X32
-    for (int l = 0; l < 3; l++) {
-      const int N = 8 << l, c = 1 << l;
-      const std::vector<uint16_t>& order = st.natural_order[order_bucket[l]];   // scan position -> stored index kx * N + ky
+    for (auto& q : im.scan_of) q = nullptr;
+    for (auto& q : im.dq) q = nullptr;
+    for (int o : {0, 2, 3, 4, 6, 7, 8}) {   // order buckets of DCT8, 16x16, 32x32, 16x8 / 8x16, 32x16 / 16x32, 64x64, 64x32 / 32x64
+      const std::vector<uint16_t>& order = st.natural_order[o];   // scan position -> stored index
       std::vector<uint16_t> inv(order.size());
       for (size_t k = 0; k < order.size(); k++) inv[order[k]] = (uint16_t)k;
-      im.scan_of[l] = A.Upload(inv);
-      im.dq[l] = A.Upload(st.dq[quant_table[l]]);
+      im.scan_of[o] = A.Upload(inv);
+    }
+    for (int q : {0, 4, 5, 6, 8, 11, 12}) im.dq[q] = A.Upload(st.dq[q]);
+    std::vector<float> rs(16 * 64, 1.0f);
+    for (int l = 0; l < 4; l++) {
+      const int N = 8 << l, c = 1 << l;
       im.basis[l] = A.Upload(st.basis[l]);
       std::vector<float> div(st.basis[l]);
       for (auto& v : div) v = v / (float)N;
@@ -329,14 +334,17 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
       for (int k = 0; k < c; k++)
         for (int n = 0; n < c; n++) small[(size_t)k * c + n] = (float)((k ? std::sqrt(2.0) : 1.0) * std::cos((2 * n + 1) * k * M_PI / (2.0 * c)));
       im.bsmall[l] = A.Upload(small);
-      auto resample = [&](int k) {   // coefficient k of an 8c-point DCT from the c-point DCT of the block means
-        if (k == 0) return 1.0;
-        const double t = k * M_PI / (2.0 * c);
-        return 1.0 / (std::cos(t / 2) * std::cos(t / 4) * std::cos(t / 8));
-      };
-      for (int ky = 0; ky < c; ky++)
-        for (int kx = 0; kx < c; kx++) im.rs[l][ky * c + kx] = (float)(resample(ky) * resample(kx));
     }
+    auto resample = [](int c, int k) {   // coefficient k of an 8c-point DCT from the c-point DCT of the block means
+      if (k == 0) return 1.0;
+      const double t = k * M_PI / (2.0 * c);
+      return 1.0 / (std::cos(t / 2) * std::cos(t / 4) * std::cos(t / 8));
+    };
+    for (int ly = 0; ly < 4; ly++)
+      for (int lx = 0; lx < 4; lx++)
+        for (int ky = 0; ky < (1 << ly); ky++)
+          for (int kx = 0; kx < (1 << lx); kx++) rs[(ly * 4 + lx) * 64 + ky * 8 + kx] = (float)(resample(1 << ly, ky) * resample(1 << lx, kx));
+    im.rs = A.Upload(rs);
   }
   // ---- 3. planes, front end
   for (int c = 0; c < 3; c++) {

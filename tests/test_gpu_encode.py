@@ -18,12 +18,12 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
 
-# effort (JxlEncoderTypes.h:29): 1..4 keep every block an 8x8 DCT, from 5 up flat regions get 16x16 / 32x32 DCTs; the oracle's
-# encoder has a matching mode for each (strategy_mode 1 / 4)
-EFFORTS = [(3, 1), (7, 4)]
+# effort (JxlEncoderTypes.h:29): 1..4 keep every block an 8x8 DCT, 5 and 6 add 16x16 / 32x32 DCTs on flat regions, from 7 (the host's
+# default) also 64x64 and the rectangular shapes; the oracle's encoder has a matching mode for each (strategy_mode 1 / 4 / 0)
+EFFORTS = [(3, 1), (5, 4), (7, 0)]
 
 
-@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "default"])
+@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "squares", "default"])
 @pytest.mark.parametrize("size,seed", [((300, 280), 3), ((520, 400), 4), ((264, 2100), 5)])
 def test_save_image_round_trip_rgba(oracle, size, seed, effort, mode):
     w, h = size
@@ -43,7 +43,7 @@ def test_save_image_round_trip_rgba(oracle, size, seed, effort, mode):
     assert got.pixels.shape == od.pixels.shape and d.max() <= 1
 
 
-@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "default"])
+@pytest.mark.parametrize("effort,mode", EFFORTS, ids=["fast", "squares", "default"])
 def test_quantised_data_matches_the_oracle_encoder(oracle, effort, mode):
     """Same pixels through both encoders, same transform set: strategies, quant field, quantised LF and HF coefficients agree except
     where a float32 rounding difference (cbrt / pow / summation order) flips a value sitting on a decision or quantisation boundary."""
@@ -53,9 +53,13 @@ def test_quantised_data_matches_the_oracle_encoder(oracle, effort, mode):
     sa, sb = a.planes["strategy"], b.planes["strategy"]
     same = sa == sb
     assert same.mean() > 0.995                       # an activity within an ulp of a threshold may tip a region the other way
+    first = sa[sa >= 0x80] & 0x7F
     if mode == 4:
-        first = sa[sa >= 0x80] & 0x7F
         assert (first == 4).sum() > 50 and (first == 5).sum() > 10, np.unique(first, return_counts=True)   # both squares really occur
+        assert set(np.unique(first).tolist()) <= {0, 4, 5}
+    elif mode == 0:
+        kinds = set(np.unique(first).tolist())
+        assert len(kinds & {6, 7, 10, 11}) >= 3 and len(kinds & {18, 19, 20}) >= 1 and kinds <= {0, 4, 5, 6, 7, 10, 11, 18, 19, 20}, kinds
     else:
         assert same.all() and ((sa & 0x7F) == 0).all()
     rq = (a.planes["raw_quant"] != b.planes["raw_quant"]) | ~same
@@ -77,12 +81,13 @@ def test_quantised_data_matches_the_oracle_encoder(oracle, effort, mode):
 def test_effort_changes_the_transform_set_and_the_rate(oracle):
     img = synth(768, 512, 23)
     fast = api.save_image(bgra_of(img), distance=1.0, effort=3)
+    squares = api.save_image(bgra_of(img), distance=1.0, effort=5)
     default = api.save_image(bgra_of(img), distance=1.0, effort=7)
     sf = oracle.decode(fast, want_dump=True).planes["strategy"]
     sd = oracle.decode(default, want_dump=True).planes["strategy"]
     assert ((sf & 0x7F) == 0).all() and ((sd & 0x7F) != 0).mean() > 0.2
-    assert len(default) < len(fast)                  # larger transforms on flat regions cost fewer bits
-    for data in (fast, default):
+    assert len(default) < len(squares) < len(fast)   # larger transforms on flat regions cost fewer bits
+    for data in (fast, squares, default):
         got = api.load_image(data)
         od = oracle.decode(data)
         assert np.abs(got.pixels.astype(int) - od.pixels.astype(int)).max() <= 1

@@ -640,6 +640,12 @@ struct VarDctEncoder {
       for (auto& t : meta_tok) n[1] += t.size();
       for (auto& t : ac_tok) n[2] += t.size();
       for (auto& t : alpha_tok) n[3] += t.size();
+      if (getenv("JXO_TOKEN_STATS")) {
+        size_t mx = 0, mxlf = 0;
+        for (auto& t : ac_tok) mx = std::max(mx, t.size());
+        for (size_t g = 0; g < lf_tok.size(); g++) mxlf = std::max(mxlf, lf_tok[g].size() + meta_tok[g].size());
+        fprintf(stderr, "[jxo] tokens: largest HF stream %zu of %llu in %zu streams; largest LF-group section %zu\n", mx, (unsigned long long)n[2], ac_tok.size(), mxlf);
+      }
       SetLastEncodeTokenCounts(n);
     }
     for (uint32_t pass = 0; pass < np; pass++) {

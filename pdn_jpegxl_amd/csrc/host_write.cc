@@ -4,6 +4,7 @@
 #include "icc.h"
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <cstring>
 #include <stdexcept>
 
@@ -165,27 +166,37 @@ void WriteDistribution(BitWriter& bw, const std::vector<int>& counts) {
   }
 }
 
+// x * log2(x): the clustering below evaluates it millions of times (64 seeds x thousands of contexts x the alphabet); counts are
+// small integers almost always, so a table replaces the library call (the code construction was 19 ms of a 4K save, 15 ms of a
+// 200 x 150 one)
+double XLog2X(uint64_t x) {
+  static std::vector<double> table;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    table.resize(1 << 16);
+    table[0] = 0;
+    for (size_t i = 1; i < table.size(); i++) table[i] = (double)i * std::log2((double)i);
+  });
+  return x < table.size() ? table[x] : (double)x * std::log2((double)x);
+}
+
 struct Hist {
   std::vector<uint64_t> c;
   uint64_t total = 0;
-  double bits = 0;   // sum -c log2(c / total)
+  double bits = 0;   // sum -c log2(c / total) = total log2(total) - sum c log2(c)
   void Finish() {
     total = 0;
     for (auto v : c) total += v;
-    bits = 0;
-    for (auto v : c) if (v) bits -= (double)v * std::log2((double)v / (double)total);
+    bits = XLog2X(total);
+    for (auto v : c) if (v) bits -= XLog2X(v);
   }
 };
 
 // extra bits when both are coded with their merged distribution; nsym: symbols that occur at all (the tail of the alphabet is empty)
 double JoinCost(const Hist& a, const Hist& b, size_t nsym) {
   if (!a.total || !b.total) return 0;
-  const uint64_t tot = a.total + b.total;
-  double e = 0;
-  for (size_t i = 0; i < nsym; i++) {
-    const uint64_t v = a.c[i] + b.c[i];
-    if (v) e -= (double)v * std::log2((double)v / (double)tot);
-  }
+  double e = XLog2X(a.total + b.total);
+  for (size_t i = 0; i < nsym; i++) e -= XLog2X(a.c[i] + b.c[i]);
   return e - a.bits - b.bits;
 }
 

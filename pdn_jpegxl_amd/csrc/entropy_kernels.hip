@@ -1355,6 +1355,70 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
     // case with one section per wavefront, i.e. small batches), stay in a loop that holds nothing but the coefficient token:
     // the general iteration below pays for both token kinds and their bookkeeping on every step.
     if (__all(!want_nz)) {
+      if (per_wave == 1 && !tab.slow) {
+        // One section per wavefront (single frames, small batches): every value of this loop is the same in all lanes, i.e. it is
+        // scalar work - and on this machine a dependent scalar operation costs a fraction of a dependent vector one (which issues
+        // every ~10 cycles).  The loop-carried state is moved to scalar registers (v_readfirstlane), table entries come back from LDS
+        // through the same door, and the recurrence state -> alias entry -> state runs on the scalar unit; only the LDS addresses and
+        // the entry store touch vector registers.
+#define JXL_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+        uint32_t s_state = JXL_RFL(state), s_nz = JXL_RFL(nzeros), s_k = JXL_RFL(k), s_prev = JXL_RFL(prev), s_epos = JXL_RFL(epos), s_it = JXL_RFL(it);
+        const uint32_t s_cov = JXL_RFL(covered), s_l2 = JXL_RFL(log2c), s_size = JXL_RFL(size), s_histo = JXL_RFL(histo);
+        uint64_t s_buf = ((uint64_t)JXL_RFL((uint32_t)(b.buf >> 32)) << 32) | JXL_RFL((uint32_t)b.buf);
+        int s_n = (int)JXL_RFL(b.n);
+        uint32_t s_rd = JXL_RFL(b.rd), s_err = 0;
+        const uint32_t la = JXL_RFL(tab.log_alpha), le = 12 - la;
+        bool stop = false;
+        do {
+          const uint32_t nzl = (s_nz + s_cov - 1) >> s_l2;
+          const uint32_t ks = s_k >> s_l2;
+          const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 7 + (ks >> 1) : 15 + (ks >> 2));
+          const uint32_t a = JXL_RFL(nnz_tab[nzl]);
+          const uint32_t cl = JXL_RFL(tab.cmap[s_histo + (a + fctx) * 2 + s_prev]);
+          const uint32_t res = s_state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
+          const uint64_t e = tab.alias[(cl << la) | i];
+          const uint32_t c = JXL_RFL(tab.cfg[cl]);
+          const uint32_t x = JXL_RFL((uint32_t)e), y = JXL_RFL((uint32_t)(e >> 32));
+          const bool gt = pos >= (x & 0xFF);
+          const uint32_t sym = gt ? ((x >> 8) & 0xFF) : i;
+          const uint32_t off = gt ? (y & 0xFFFF) + pos : pos;
+          const uint32_t freq = gt ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
+          s_state = freq * (s_state >> 12) + off;
+          if (s_state < 65536u) {
+            if (s_n <= 32) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRing - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }
+            s_state = (s_state << 16) | ((uint32_t)s_buf & 0xFFFFu);
+            s_buf >>= 16; s_n -= 16;
+          }
+          uint32_t u = sym;
+          const uint32_t se = c & 0xF, split = 1u << se;
+          if (sym >= split) {
+            const uint32_t msb = (c >> 4) & 0xF, lsb = (c >> 8) & 0xF;
+            const uint32_t nb = se - (msb + lsb) + ((sym - split) >> (msb + lsb)), nbr = nb > 32 ? 32 : nb;
+            if (s_n <= 32) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRing - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }
+            const uint32_t bits = (uint32_t)(s_buf & (((uint64_t)1 << nbr) - 1));
+            s_buf >>= nbr; s_n -= (int)nbr;
+            const uint32_t low = sym & ((1u << lsb) - 1), hi = (1u << msb) | ((sym >> lsb) & ((1u << msb) - 1));
+            u = (uint32_t)(((((uint64_t)hi << (nb & 63)) | bits) << lsb) | low);
+          }
+          s_it++;
+          if (u) {
+            const int32_t v = UnpackSigned(u);
+            if (v != (int32_t)(int16_t)v) s_err |= kErrRange;
+            ent[s_epos++] = s_k | (uint32_t)v << 16;
+            s_prev = 1;
+            if (--s_nz == 0) stop = true;
+          } else {
+            s_prev = 0;
+          }
+          if (++s_k >= s_size && s_nz != 0) { s_err |= kErrBitstream; stop = true; }
+        } while (!stop && (s_it & (kTop - 1)) != 0);
+#undef JXL_RFL
+        state = s_state; nzeros = s_nz; k = s_k; prev = s_prev; epos = s_epos; it = s_it;
+        b.buf = s_buf; b.n = s_n; b.rd = s_rd;
+        err |= s_err;
+        if (s_nz == 0 && !s_err) { want_nz = true; ci++; }
+        continue;
+      }
       for (;;) {
         const uint32_t nzl = (nzeros + covered - 1) >> log2c;
         const uint32_t ks = k >> log2c;

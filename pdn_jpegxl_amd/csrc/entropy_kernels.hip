@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         do {
           const uint32_t nzl = (s_nz + s_cov - 1) >> s_l2;
           const uint32_t ks = s_k >> s_l2;
-          const uint32_t fctx = ks < 16 ? ks - 1 : (ks < 32 ? 7 + (ks >> 1) : 15 + (ks >> 2));
+          const uint32_t fctx = min(ks - 1, min(7 + (ks >> 1), 15 + (ks >> 2)));   // the three-piece position context, without branches
           const uint32_t a = JXL_RFL(nnz_tab[nzl]);
           const uint32_t cl = JXL_RFL(tab.cmap[s_histo + (a + fctx) * 2 + s_prev]);
           const uint32_t res = s_state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);

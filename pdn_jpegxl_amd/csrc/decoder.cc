@@ -617,7 +617,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // lane walking its own divergent stream) took 68 ms against 33 ms for the four of a 4K frame; one group per wavefront is no faster
   // for a single frame and much slower for a batch (384 frames: 44 -> 67 ms, four times the wavefronts for the same tokens).  So: four
   // per wavefront, more only when a batch brings tens of thousands of LF groups.
-  int lf_per_wave = 4;
+  // LF sections per wavefront: one while the batch is small (the wavefront's recurrence then runs on the scalar unit: lower latency),
+  // four for large batches (fewer wavefronts and table copies for the same latency-bound time), more only for huge ones
+  int lf_per_wave = total_lf <= 256 ? 1 : 4;
   while (lf_per_wave < 64 && total_lf / lf_per_wave > 4096) lf_per_wave *= 2;
   if (const char* e = getenv("JXLHIP_LF_PER_WAVE")) lf_per_wave = std::max(1, atoi(e));   // experiment knob
   int n_lf_ans = 0;
@@ -640,6 +642,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   imgs.assign(n + n_extra, DevImage());
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
+  int max_mclusters = 0;   // most clusters of any frame's Modular code (sizes the direct tables of one-section wavefronts)
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
   bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
@@ -911,6 +914,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
     lds_lf = std::max(lds_lf, (size_t)lf_per_wave * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = std::max(lds_alpha, (size_t)per_alpha_wg * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
+    max_mclusters = std::max<int>(max_mclusters, (int)f.mcode.cfg.size());
     max_groups = std::max<int>(max_groups, (int)f.ng);
     // LF groups that intersect the decoded group rows (8 group rows per LF group row); HF groups of the decoded rows; alpha of the band
     const uint32_t lfy0 = (uint32_t)d.dec_gy0 / 8, lfy1 = ((uint32_t)d.dec_gy1 + 7) / 8;
@@ -998,8 +1002,16 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (!(skip_stages & 1)) HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
+  // wavefronts that decode one section get per-residue tables of the Modular code (16 KB per cluster) when they fit
+  auto direct_room = [&](size_t lds, int per_wave) {
+    if (per_wave != 1 || lds > kLdsMax || getenv("JXLHIP_NO_DIRECT")) return 0;
+    return std::min<int>(max_mclusters, (int)((kLdsMax - lds) >> 14));
+  };
+  const int direct_lf = direct_room(lds_lf + 16, lf_per_wave), direct_alpha = direct_room(lds_alpha + 16, per_alpha_wg);
+  if (direct_lf) lds_lf += 16 + ((size_t)direct_lf << 14);
+  if (direct_alpha) lds_alpha += 16 + ((size_t)direct_alpha << 14);
   if (!(skip_stages & 1)) {
-  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, s_lf);
+  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, direct_lf, s_lf);
   Mark("lf_ans", s_lf, 0);
   LaunchLfFinish(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, s_lf);
   LaunchHfBlockList(d_imgs, n, max_groups, s_lf);
@@ -1018,7 +1030,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages
   if (any_alpha && !(skip_stages & 4))
-    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, s_hf);
+    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, direct_alpha, s_hf);
   Mark("alpha_ans", s_hf, 1);
   if (debug_taps) {   // the quantised coefficients as dense planes (every frame has its own planes in this mode)
     taps.assign(n, Tap());
@@ -1177,7 +1189,7 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
   uint64_t lf_end = 0;
   if (e == hipSuccess) {
     const size_t lds = 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + 8 + 8 * f.mcode.alias.size() + 4 * f.mcode.cfg.size() + f.mcode.ctx_map.size();
-    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, 64, lds <= 150 * 1024 ? lds : 0, own_stream);
+    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, 64, lds <= 150 * 1024 ? lds : 0, 0, own_stream);
     e = hipStreamSynchronize(own_stream);
   }
   if (e == hipSuccess) e = hipMemcpy(st_words, d + o_status, 64, hipMemcpyDeviceToHost);

@@ -169,6 +169,7 @@ struct CodeTab {
   typename AS<kLds>::U8 cmap;
   typename AS<kLds>::U32 cfg;     // split | msb << 4 | lsb << 8 | degenerate << 12 | symbol << 16
   typename AS<kLds>::U64 alias;
+  typename AS<kLds>::U32 direct;  // per cluster 4096 entries, one per state residue: freq - 1 | offset << 12 | symbol << 24 (or null)
   uint32_t log_alpha;
   uint32_t slow;        // DevCode::slow (uniform over the workgroup: one image's code)
   const DevCode* dc;    // the prefix / LZ77 parameters stay in global memory
@@ -334,8 +335,29 @@ __device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeT
 }
 
 // Cooperative copy of a code's tables into LDS; returns the carved end offset.
-__device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, const DevCode& dc, CodeTab<true>& t, int tid, int nt) {
+__device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, const DevCode& dc, CodeTab<true>& t, int tid, int nt,
+                                            int direct_clusters = 0) {
   const uint32_t na = (dc.slow & 1) ? 0u : dc.num_clusters << dc.log_alpha;   // prefix codes have no alias tables
+  t.direct = nullptr;
+  if (direct_clusters > 0 && !dc.slow && dc.num_clusters <= (uint32_t)direct_clusters) {
+    // The alias tables spelled out per state residue, for wavefronts that decode ONE section: such a wavefront issues an instruction
+    // every four to five cycles whatever unit executes it, so its time per token is its instruction count, and the alias
+    // arithmetic (bucket, cutoff compare, three selects) is a third of the token.  16 KB per cluster, built by all 64 lanes.
+    off = (off + 15) & ~(size_t)15;
+    JXL_LDS uint32_t* sd = (JXL_LDS uint32_t*)(smem + off); off += (size_t)dc.num_clusters << 14;
+    const uint32_t la = dc.log_alpha, le = 12 - la;
+    for (uint32_t r = tid; r < (dc.num_clusters << 12); r += nt) {
+      const uint32_t cl = r >> 12, res = r & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
+      const uint64_t e = dc.alias[(cl << la) + i];
+      const uint32_t x = (uint32_t)e, y = (uint32_t)(e >> 32);
+      const bool g = pos >= (x & 0xFF);
+      const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
+      const uint32_t o = g ? (y & 0xFFFF) + pos : pos;
+      const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
+      sd[r] = ((freq - 1) & 0xFFF) | ((o & 0xFFF) << 12) | (sym << 24);
+    }
+    t.direct = sd;
+  }
   off = (off + 7) & ~(size_t)7;
   JXL_LDS uint64_t* sa = (JXL_LDS uint64_t*)(smem + off); off += (size_t)na * 8;
   JXL_LDS uint32_t* sc = (JXL_LDS uint32_t*)(smem + off); off += (size_t)dc.num_clusters * 4;
@@ -348,7 +370,7 @@ __device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, c
 }
 
 __device__ __forceinline__ void GlobalCode(const DevCode& dc, CodeTab<false>& t) {
-  t.cmap = dc.ctx_map; t.cfg = dc.cfg; t.alias = dc.alias; t.log_alpha = dc.log_alpha; t.slow = dc.slow; t.dc = &dc;
+  t.cmap = dc.ctx_map; t.cfg = dc.cfg; t.alias = dc.alias; t.direct = nullptr; t.log_alpha = dc.log_alpha; t.slow = dc.slow; t.dc = &dc;
 }
 
 // ------------------------------------------------------------------ Modular channel
@@ -475,7 +497,7 @@ struct WpState {
 // Decodes one channel (w x h) into `out` (row stride `stride`).  Every property 0..14 and every predictor
 // except the weighted one are supported; the host rejects trees that need more.
 template <bool kLds>
-__device__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan,
+__device__ __forceinline__ void ModularChannel(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan,
                                int stream_id, int w, int h, int32_t* out_generic, int stride, const RowBuf<kLds>& rbuf,
                                int32_t* wp_scratch = nullptr) {
   JXL_GLB int32_t* const out = G(out_generic);
@@ -660,9 +682,73 @@ __device__ int ClassifyChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree
   return all_const ? 2 : 1;
 }
 
+// One row of a row-static channel decoded by a wavefront that owns ONE section (single frames, small batches).  The recurrence is
+// uniform, so it runs on the scalar unit: ANS state, bit buffer and West sample live in scalar registers, the direct-table entry and
+// the window words come back from LDS through v_readfirstlane, only the sample store is a vector instruction.  A lone wavefront
+// issues one instruction every four to five cycles whichever unit executes it, so what counts here is the instruction count per
+// token: sixteen tokens unrolled between top-ups (no loop or address arithmetic per token), the common leaf (multiplier 1, offset
+// 0, predictor applied in phase B) without the multiply / offset / West instructions.
+#define JXL_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+template <bool kPlain>
+__device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, const JXL_LDS uint32_t* dt, uint32_t cfg, uint32_t mul, uint32_t off,
+                                          bool add_w, uint32_t W, uint32_t& first_out, JXL_GLB int32_t* row, int w) {
+  uint32_t s_state = JXL_RFL(state), s_w = JXL_RFL(W), s_first = 0, s_rd = JXL_RFL(b.rd);
+  uint64_t s_buf = ((uint64_t)JXL_RFL((uint32_t)(b.buf >> 32)) << 32) | JXL_RFL((uint32_t)b.buf);
+  int s_n = (int)JXL_RFL(b.n);
+  const uint32_t s_cfg = JXL_RFL(cfg), s_mul = JXL_RFL(mul), s_off = JXL_RFL(off);
+  const uint32_t se = s_cfg & 0xF, split = 1u << se, msb = (s_cfg >> 4) & 0xF, lsb = (s_cfg >> 8) & 0xF;
+  const bool s_addw = JXL_RFL(add_w ? 1u : 0u) != 0;
+  const int sw = (int)JXL_RFL(w);
+  auto word = [&]() {
+    if (s_n <= 32) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRingWords - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }
+  };
+  auto token = [&](int x) {
+    const uint32_t e = JXL_RFL(dt[s_state & 0xFFF]);
+    const uint32_t hi = s_state >> 12;
+    s_state = (e & 0xFFF) * hi + hi + ((e >> 12) & 0xFFF);
+    if (s_state < 65536u) {
+      word();
+      s_state = (s_state << 16) | ((uint32_t)s_buf & 0xFFFFu);
+      s_buf >>= 16; s_n -= 16;
+    }
+    const uint32_t sym = e >> 24;
+    uint32_t u = sym;
+    if (sym >= split) {
+      const uint32_t nb = se - (msb + lsb) + ((sym - split) >> (msb + lsb)), nbr = nb > 32 ? 32 : nb;
+      word();
+      const uint32_t bits = (uint32_t)(s_buf & (((uint64_t)1 << nbr) - 1));
+      s_buf >>= nbr; s_n -= (int)nbr;
+      const uint32_t low = sym & ((1u << lsb) - 1), top = (1u << msb) | ((sym >> lsb) & ((1u << msb) - 1));
+      u = (uint32_t)(((((uint64_t)top << (nb & 63)) | bits) << lsb) | low);
+    }
+    if constexpr (kPlain) {
+      row[x] = UnpackSigned(u);
+    } else {
+      const uint32_t val = (uint32_t)UnpackSigned(u) * s_mul + s_off + (s_addw ? s_w : 0u);
+      row[x] = (int32_t)val;
+      s_w = val;
+      s_first = x == 0 ? val : s_first;
+    }
+  };
+  int x0 = 0;
+  for (; x0 + kTopUpEvery <= sw; x0 += kTopUpEvery) {
+    b.rd = s_rd;
+    b.TopUp();
+#pragma unroll
+    for (int k = 0; k < kTopUpEvery; k++) token(x0 + k);
+  }
+  if (x0 < sw) {
+    b.rd = s_rd;
+    b.TopUp();
+    for (int x = x0; x < sw; x++) token(x);
+  }
+  state = s_state; b.buf = s_buf; b.n = s_n; b.rd = s_rd;
+  first_out = s_first;
+}
+
 // Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
 template <bool kLds>
-__device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
+__device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
                                   int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr,
                                   const RowBuf<kLds>* lane_rows = nullptr) {
   ChanDesc d;
@@ -709,6 +795,15 @@ __device__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kL
     }
     // sixteen tokens per top-up of the bit window; no per-token bookkeeping beyond the decode itself
     uint32_t first = 0;
+    if constexpr (kLds) {
+      if (tab.direct) {   // one section per wavefront: the scalar-unit loop over the direct table of the row's cluster
+        const JXL_LDS uint32_t* const dt = tab.direct + (cl << 12);
+        if (mul == 1 && off == 0 && needs_n) RowScalar<true>(b, state, dt, cfg, 1u, 0u, false, W, first, row, w);
+        else RowScalar<false>(b, state, dt, cfg, mul, off, add_w, W, first, row, w);
+        first_prev = first;
+        continue;
+      }
+    }
     uint64_t entry = AnsPrefetch<kLds>(state, abase, tab.log_alpha);
     for (int x0 = 0; x0 < w; x0 += kTopUpEvery) {
       b.TopUp();
@@ -907,14 +1002,15 @@ struct ModTables {
 
 // Stages the MA tree + modular code of `im` (LDS variant) or points at them in global memory.
 template <bool kLds>
-__device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem, size_t off, ModTables<kLds>& t, int tid, int nt) {
+__device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem, size_t off, ModTables<kLds>& t, int tid, int nt,
+                                              int direct_clusters = 0) {
   if constexpr (kLds) {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     off = (off + 15) & ~(size_t)15;
     JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
     for (int i = tid; i < im.tree_size; i += nt) st[i] = ((const I4*)im.tree)[i];
     t.tree = st;
-    StageCode(lds, off, im.mcode, t.tab, tid, nt);
+    StageCode(lds, off, im.mcode, t.tab, tid, nt, direct_clusters);
     __syncthreads();
   } else {
     GlobalCode(im.mcode, t.tab);
@@ -928,14 +1024,14 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds>
-__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int direct_clusters) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   ModTables<kLds> mt;
   // `slots` lanes of the wavefront decode (the launch's sections per workgroup): the bit windows take slots * 128 B of LDS, not 8 KB -
   // LDS is what decides whether this kernel can share a CU with the HF decoder of the batch before
-  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64);
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 ? direct_clusters : 0);
   const int lane = threadIdx.x;
   if (lane >= task.count || lane >= slots) return;
   const int g = task.first + lane;
@@ -1513,14 +1609,14 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds>
-__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
+__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int direct_clusters) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   if (!im.has_alpha || im.alpha_in_global) return;
   ModTables<kLds> mt;
   const int slots = 64 / lane_stride;
-  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64);
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 ? direct_clusters : 0);
   const int lane = threadIdx.x;
   if (lane >= slots || lane >= task.count) return;
   const int g = task.first + lane;
@@ -1845,13 +1941,13 @@ static void RaiseLds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, hipStream_t s) {
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int direct_clusters, hipStream_t s) {
   if (ntasks <= 0) return;   // slots: sections per workgroup (lanes that decode); lds_bytes: their bit windows + the tables (0: tables stay global)
   if (lds_bytes) {
     RaiseLds((const void*)lf_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots);
+    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots, direct_clusters);
   } else {
-    hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), (size_t)slots * kRingWords * 4, s, imgs, tasks, slots);
+    hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), (size_t)slots * kRingWords * 4, s, imgs, tasks, slots, 0);
   }
 }
 
@@ -1880,13 +1976,13 @@ void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int
   }
 }
 
-void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, hipStream_t s) {
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int direct_clusters, hipStream_t s) {
   if (nwg <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)alpha_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride, direct_clusters);
   } else {
-    hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), (size_t)(64 / lane_stride) * kRingWords * 4, s, imgs, tasks, lane_stride);
+    hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), (size_t)(64 / lane_stride) * kRingWords * 4, s, imgs, tasks, lane_stride, 0);
   }
 }
 

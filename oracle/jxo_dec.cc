@@ -322,6 +322,7 @@ struct FrameDecoder {
     std::vector<int32_t> q[3];
     std::vector<float> coef[3];
     std::vector<float> pix;
+    size_t stat_coef = 0, stat_nnz = 0, stat_nonzero = 0;   // JXO_TOKEN_STATS: tokens of this section (sizing of decoder measurements)
     for (int by = 0; by < bh; by++) {
       for (int bx = 0; bx < bw; bx++) {
         size_t cell = (size_t)(by0 + by) * w8 + bx0 + bx;
@@ -350,6 +351,7 @@ struct FrameDecoder {
           uint32_t block_ctx = bctx.Context(lf_idx.empty() ? 0 : lf_idx[cell], raw_quant[cell], ord, c);
           uint32_t nzeros = rd.Read(ctx_offset + bctx.NonZeroContext(predicted, block_ctx));
           JXO_CHECK(nzeros + covered <= size, "too many nonzero coefficients");
+          stat_nnz++; stat_nonzero += nzeros;
           uint8_t fill = (uint8_t)((nzeros + covered - 1) >> log2c);
           for (int iy = 0; iy < cy; iy++)
             for (int ix = 0; ix < cx; ix++) nz[c][(by + iy) * 32 + bx + ix] = fill;
@@ -360,6 +362,7 @@ struct FrameDecoder {
           for (uint32_t k = covered; k < size && nzeros != 0; k++) {
             uint32_t ctx = histo_offset + ZeroDensityContext(nzeros, k, covered, log2c, prev);
             uint32_t u = rd.Read(ctx);
+            stat_coef++;
             int32_t v = (int32_t)UnpackSigned(u);
             q[c][ordp[k]] += v * (1 << shift);
             prev = u != 0;
@@ -373,6 +376,8 @@ struct FrameDecoder {
       }
     }
     JXO_CHECK(rd.CheckFinal(), "AC group ANS final state");
+    if (getenv("JXO_TOKEN_STATS"))
+      fprintf(stderr, "[jxo] pass %u group (%d,%d): %zu block-channels, %zu coefficient tokens, %zu non-zero\n", pass, gx, gy, stat_nnz, stat_coef, stat_nonzero);
   }
 
   // Dequantise (+CfL), insert LLF, inverse transform, store pixels.

@@ -1418,6 +1418,16 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   int ci = 3;
   uint32_t nzeros = 0, k = 0, prev = 0, histo = 0;
   bool want_nz = true;
+  // one-section wavefronts: do all clusters share one hybrid-integer configuration?  (then the token loop keeps it in a register)
+  uint32_t cfg_uni = 0;
+  bool cfg_is_uni = false;
+  if (per_wave == 1 && !tab.slow) {
+    cfg_uni = tab.cfg[0] & 0xFFF;
+    cfg_is_uni = true;
+    for (uint32_t i = 1; i < tab.dc->num_clusters; i++) cfg_is_uni &= (tab.cfg[i] & 0xFFF) == cfg_uni;
+    cfg_uni = (uint32_t)__builtin_amdgcn_readfirstlane((int)cfg_uni);
+    cfg_is_uni = __builtin_amdgcn_readfirstlane((int)cfg_is_uni) != 0;
+  }
   while (!err) {
     if ((it & (kTop - 1)) == 0) {
       b.TopUp();
@@ -1458,22 +1468,28 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         // through the same door, and the recurrence state -> alias entry -> state runs on the scalar unit; only the LDS addresses and
         // the entry store touch vector registers.
 #define JXL_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+        // A lone wavefront issues one instruction every four cycles or so, and every LDS lookup on the chain adds ~80: the loop is
+        // written for few instructions and few dependent lookups - the tokens a period or the block still allows are counted down
+        // (no per-token stop conditions), the non-zero-count bucket is looked up again only after a non-zero coefficient, the range
+        // check is one OR per coefficient, and a code whose clusters share one hybrid-integer configuration skips that lookup.
         uint32_t s_state = JXL_RFL(state), s_nz = JXL_RFL(nzeros), s_k = JXL_RFL(k), s_prev = JXL_RFL(prev), s_epos = JXL_RFL(epos), s_it = JXL_RFL(it);
         const uint32_t s_cov = JXL_RFL(covered), s_l2 = JXL_RFL(log2c), s_size = JXL_RFL(size), s_histo = JXL_RFL(histo);
         uint64_t s_buf = ((uint64_t)JXL_RFL((uint32_t)(b.buf >> 32)) << 32) | JXL_RFL((uint32_t)b.buf);
         int s_n = (int)JXL_RFL(b.n);
-        uint32_t s_rd = JXL_RFL(b.rd), s_err = 0;
+        uint32_t s_rd = JXL_RFL(b.rd), s_rng = 0;
         const uint32_t la = JXL_RFL(tab.log_alpha), le = 12 - la;
-        bool stop = false;
-        do {
-          const uint32_t nzl = (s_nz + s_cov - 1) >> s_l2;
+        const uint32_t left = kTop - (s_it & (kTop - 1)), room = s_size > s_k ? s_size - s_k : 0u;
+        const uint32_t cnt0 = min(left, room);
+        uint32_t cnt = cnt0;
+        uint32_t s_a = s_histo + 2 * JXL_RFL(nnz_tab[(s_nz + s_cov - 1) >> s_l2]);
+        if (cnt) do {
           const uint32_t ks = s_k >> s_l2;
           const uint32_t fctx = min(ks - 1, min(7 + (ks >> 1), 15 + (ks >> 2)));   // the three-piece position context, without branches
-          const uint32_t a = JXL_RFL(nnz_tab[nzl]);
-          const uint32_t cl = JXL_RFL(tab.cmap[s_histo + (a + fctx) * 2 + s_prev]);
+          const uint32_t cl = JXL_RFL(tab.cmap[s_a + fctx * 2 + s_prev]);
           const uint32_t res = s_state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
           const uint64_t e = tab.alias[(cl << la) | i];
-          const uint32_t c = JXL_RFL(tab.cfg[cl]);
+          uint32_t c = cfg_uni;
+          if (!cfg_is_uni) c = JXL_RFL(tab.cfg[cl]);
           const uint32_t x = JXL_RFL((uint32_t)e), y = JXL_RFL((uint32_t)(e >> 32));
           const bool gt = pos >= (x & 0xFF);
           const uint32_t sym = gt ? ((x >> 8) & 0xFF) : i;
@@ -1496,18 +1512,23 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
             const uint32_t low = sym & ((1u << lsb) - 1), hi = (1u << msb) | ((sym >> lsb) & ((1u << msb) - 1));
             u = (uint32_t)(((((uint64_t)hi << (nb & 63)) | bits) << lsb) | low);
           }
-          s_it++;
+          cnt--;
+          s_prev = 0;
           if (u) {
             const int32_t v = UnpackSigned(u);
-            if (v != (int32_t)(int16_t)v) s_err |= kErrRange;
+            s_rng |= (uint32_t)(v + 0x8000);   // a value outside int16 leaves a bit above bit 15
             ent[s_epos++] = s_k | (uint32_t)v << 16;
             s_prev = 1;
-            if (--s_nz == 0) stop = true;
+            s_k++;
+            if (--s_nz == 0) break;
+            s_a = s_histo + 2 * JXL_RFL(nnz_tab[(s_nz + s_cov - 1) >> s_l2]);
           } else {
-            s_prev = 0;
+            s_k++;
           }
-          if (++s_k >= s_size && s_nz != 0) { s_err |= kErrBitstream; stop = true; }
-        } while (!stop && (s_it & (kTop - 1)) != 0);
+        } while (cnt);
+        s_it += cnt0 - cnt;
+        uint32_t s_err = s_rng > 0xFFFFu ? (uint32_t)kErrRange : 0u;
+        if (s_nz != 0 && s_k >= s_size) s_err |= kErrBitstream;
 #undef JXL_RFL
         state = s_state; nzeros = s_nz; k = s_k; prev = s_prev; epos = s_epos; it = s_it;
         b.buf = s_buf; b.n = s_n; b.rd = s_rd;

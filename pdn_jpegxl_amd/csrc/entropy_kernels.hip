@@ -1482,10 +1482,15 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         const uint32_t cnt0 = min(left, room);
         uint32_t cnt = cnt0;
         uint32_t s_a = s_histo + 2 * JXL_RFL(nnz_tab[(s_nz + s_cov - 1) >> s_l2]);
+        uint32_t s_cidx = 0xFFFFFFFFu, s_cl = 0;
         if (cnt) do {
           const uint32_t ks = s_k >> s_l2;
           const uint32_t fctx = min(ks - 1, min(7 + (ks >> 1), 15 + (ks >> 2)));   // the three-piece position context, without branches
-          const uint32_t cl = JXL_RFL(tab.cmap[s_a + fctx * 2 + s_prev]);
+          // inside a run of zeros the context only moves when the position context does (every second / fourth position from 16 / 32
+          // on): the cluster of the last lookup is kept while the context-map index stays the same
+          const uint32_t cidx = s_a + fctx * 2 + s_prev;
+          if (cidx != s_cidx) { s_cl = JXL_RFL(tab.cmap[cidx]); s_cidx = cidx; }
+          const uint32_t cl = s_cl;
           const uint32_t res = s_state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
           const uint64_t e = tab.alias[(cl << la) | i];
           uint32_t c = cfg_uni;

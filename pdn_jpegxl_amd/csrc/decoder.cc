@@ -408,12 +408,19 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // Modular frames whose MA tree looks at decoded neighbours take the generic per-lane path: give it LDS row buffers (groups of up to
   // 256 columns); with the weighted predictor its per-sample state goes to LDS as well, which limits a workgroup to 8 sections
   int mod_lanes = 64, mod_rb = 0, mod_wp_lds = 0;
+  size_t total_mod_sections = 0;
+  int max_mod_clusters = 0;
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok || frames[i].encoding != 1) continue;
     if (!frames[i].tree_row_static && frames[i].group_dim <= 256) mod_rb = 256;
     if (frames[i].tree_uses_wp && frames[i].group_dim <= 256) { mod_wp_lds = 1; mod_lanes = 8; }
+    total_mod_sections += frames[i].single ? 1 : 1 + (size_t)frames[i].nlf + frames[i].ng;
+    max_mod_clusters = std::max<int>(max_mod_clusters, (int)frames[i].mcode.cfg.size());
   }
   if (!mod_rb) { mod_wp_lds = 0; mod_lanes = 64; }
+  // few sections (one frame, a small batch): one section per wavefront - no divergence between sections, and row-static channels
+  // decode on the scalar unit from per-residue tables (see the LF launch below)
+  if (total_mod_sections <= 512 && !getenv("JXLHIP_MOD_LANES64")) mod_lanes = 1;
   size_t chunk_pix = 0;   // padded pixels of the largest VarDCT frame of the batch
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
@@ -1063,8 +1070,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
+    int direct_mod = 0;
+    if (mod_lanes == 1 && lds_mod + 16 <= kLdsMax && !getenv("JXLHIP_NO_DIRECT")) direct_mod = std::min<int>(max_mod_clusters, (int)((kLdsMax - lds_mod - 16) >> 14));
+    if (direct_mod) lds_mod += 16 + ((size_t)direct_mod << 14);
     LaunchModularAns(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
-                     max_mod_coded, mod_lanes, mod_rb, mod_wp_lds, stream);
+                     max_mod_coded, mod_lanes, mod_rb, mod_wp_lds, direct_mod, stream);
     for (auto& op : mod_ops) {
       if (op.kind == 3) LaunchModularPalette(op.a, op.b, op.out, op.nout, op.type, op.rw, op.rh, op.status, stream);   // a: palette, b: indices (rw x rh)
       else LaunchModularOp(op.kind, op.a, op.b, op.c, op.aw, op.ah, op.rw, op.rh, op.type, stream);

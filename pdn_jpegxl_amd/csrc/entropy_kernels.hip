@@ -1757,7 +1757,7 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // Phase A: one lane per section.  A frame with a single TOC entry is one bit stream: its lane walks global, LF group and pass
 // group one after the other.
 template <bool kLds>
-__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds) {
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int direct_clusters) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
@@ -1767,7 +1767,7 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
   const size_t wp_ints = (size_t)10 * (rb_width + 2);
   const size_t off_tab = off_wp + (wp_lds ? (size_t)lanes * wp_ints * 4 : 0);
   ModTables<kLds> mt;
-  LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64);
+  LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64, lanes == 1 ? direct_clusters : 0);
   const int lane = threadIdx.x;
   if (lane >= task.count || lane >= lanes) return;
   RowBuf<kLds> rows;
@@ -2013,15 +2013,15 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
 }
 
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      int lanes, int rb_width, int wp_lds, hipStream_t s) {
+                      int lanes, int rb_width, int wp_lds, int direct_clusters, hipStream_t s) {
   if (ntasks <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds);
+    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds, direct_clusters);
   } else {
     const size_t lds = (size_t)64 * kRingWords * 4 + (size_t)lanes * rb_width * 4 + (wp_lds ? (size_t)lanes * 10 * (rb_width + 2) * 4 : 0);
     RaiseLds((const void*)modular_ans_kernel<false>, lds);
-    hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), lds, s, imgs, tasks, lanes, rb_width, wp_lds);
+    hipLaunchKernelGGL(modular_ans_kernel<false>, dim3(ntasks), dim3(64), lds, s, imgs, tasks, lanes, rb_width, wp_lds, 0);
   }
   hipLaunchKernelGGL(modular_finish_kernel, dim3(max_sections * max_coded, nimg), dim3(64), 0, s, imgs, max_coded);
 }

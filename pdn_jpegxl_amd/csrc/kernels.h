@@ -20,7 +20,7 @@ void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream
 // lanes: sections per workgroup; rb_width > 0: previous-row buffers (and, with wp_lds, the weighted-predictor state) of the generic
 // lane path live in LDS
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      int lanes, int rb_width, int wp_lds, hipStream_t s);
+                      int lanes, int rb_width, int wp_lds, int direct_clusters, hipStream_t s);
 void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
 // inverse Palette: out[k][i] = palette[k * nb_colors + index[i]] for the w x h samples of the index channel; indices outside the
 // stored palette (implicit / delta colours) raise the image's error flag

@@ -642,7 +642,11 @@ struct WaveWriter {
 };
 
 // Reverse pass of one token stream (its flushes are recorded in the token array); returns the final state on every lane.
+// kLdsRmap: the code's slot map was staged in LDS (the Modular code; the HF code's 512 KB map stays in global memory)
+template <bool kLdsRmap>
 __device__ uint32_t ReversePass(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveScratch* sc, int lane) {
+  typedef const __attribute__((address_space(3))) uint16_t* LdsU16;
+  const LdsU16 lds_rmap = kLdsRmap ? (LdsU16)code.rmap : (LdsU16) nullptr;
   const DevToken kNone = {0u, 0u};
   const int64_t nblk = ((int64_t)n + 63) >> 6;
   uint32_t state = 0x130000u;   // lane 0's copy is the real one
@@ -657,32 +661,37 @@ __device__ uint32_t ReversePass(DevToken* tok, uint32_t n, const EncCodeDev& cod
       const uint32_t cl = code.ctx_map[t.ctx];
       uint32_t sym, nb, bits;
       HybridD(t.value, &sym, &nb, &bits);
-      const uint32_t f = code.freq[cl * kEncSyms + sym];
-      sc->freq[lane] = f;
-      sc->rcp[lane] = 1.0f / (float)max(f, 1u);
-      sc->rbase[lane] = cl * 4096 + code.start[cl * kEncSyms + sym];
-      WaveSync();
-      if (lane == 0) {
-        const int cnt = (int)min<int64_t>(64, (int64_t)n - b * 64);
-#pragma unroll 4
+      // The recurrence runs on the scalar unit (every value in it is uniform): lane k keeps token k's frequency, reciprocal and slot
+      // base in registers, the loop fetches them with v_readlane, divides by multiply-high with one fix-up and leaves the flush
+      // in LDS - a dependent scalar operation costs less than half a dependent vector one on this machine, and the only
+      // lookup left on the chain is the slot map.
+      const uint32_t f = max((uint32_t)code.freq[cl * kEncSyms + sym], 1u);
+      // floor(2^32 / f) (quotient estimate q or q - 1): exact in double, the fraction of 2^32 / f is 0 or at least 1 / 4096
+      const uint32_t rcp = f == 1 ? 0xFFFFFFFFu : (uint32_t)(4294967296.0 / (double)f);
+      const uint32_t rbase = cl * 4096 + code.start[cl * kEncSyms + sym];
+      uint32_t fl = 0;
+      {
+        uint32_t s_state = (uint32_t)__builtin_amdgcn_readfirstlane((int)state);
+        const int cnt = __builtin_amdgcn_readfirstlane((int)min<int64_t>(64, (int64_t)n - b * 64));
         for (int k = cnt - 1; k >= 0; k--) {
-          const uint32_t fk = sc->freq[k];
+          const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)f, k);
+          const uint32_t rk = (uint32_t)__builtin_amdgcn_readlane((int)rcp, k);
+          const uint32_t bk = (uint32_t)__builtin_amdgcn_readlane((int)rbase, k);
           uint32_t flush = 0;
-          if ((state >> 20) >= fk) { flush = 0x10000u | (state & 0xFFFF); state >>= 16; }
-          // state / fk: the float estimate is within one of the quotient (state < fk << 20, 24-bit mantissas); fixed up exactly
-          uint32_t qd = (uint32_t)((float)state * sc->rcp[k]);
-          int32_t rm = (int32_t)(state - __umul24(qd, fk));   // qd < 2^20 + 2, fk <= 4096: a full-rate 24-bit multiply
-          const bool under = rm < 0;
-          qd -= under ? 1u : 0u; rm += under ? (int32_t)fk : 0;
-          const bool over = rm >= (int32_t)fk;
-          qd += over ? 1u : 0u; rm -= over ? (int32_t)fk : 0;
-          if ((uint32_t)rm >= fk) { qd = state / fk; rm = (int32_t)(state - qd * fk); }   // never expected: the exact division
-          state = (qd << 12) + code.rmap[(size_t)sc->rbase[k] + (uint32_t)rm];
-          sc->flush[k] = flush;
+          if ((s_state >> 20) >= fk) { flush = 0x10000u | (s_state & 0xFFFF); s_state >>= 16; }
+          uint32_t qd = __umulhi(s_state, rk);
+          uint32_t rm = s_state - qd * fk;
+          if (rm >= fk) { qd++; rm -= fk; }
+          const uint32_t slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(kLdsRmap ? lds_rmap[bk + rm] : code.rmap[(size_t)bk + rm]));
+          s_state = (qd << 12) + slot;
+          sc->flush[k] = flush;   // every lane stores the same word: off the chain, read back per lane below
         }
+        state = s_state;
       }
       WaveSync();
-      if (valid) tok[idx].ctx = sc->flush[lane];
+      fl = sc->flush[lane];
+      WaveSync();
+      if (valid) tok[idx].ctx = fl;
     }
   }
   return (uint32_t)__shfl((int)state, 0);
@@ -713,8 +722,9 @@ __device__ void ForwardPass(const DevToken* tok, uint32_t n, uint32_t state, Wav
 }
 
 
+template <bool kLdsRmap>
 __device__ void EncodeStream(DevToken* tok, uint32_t n, const EncCodeDev& code, WaveWriter& w, WaveScratch* sc) {
-  const uint32_t state = ReversePass(tok, n, code, sc, w.lane);
+  const uint32_t state = ReversePass<kLdsRmap>(tok, n, code, sc, w.lane);
   ForwardPass(tok, n, state, w);
 }
 
@@ -790,7 +800,7 @@ __global__ __launch_bounds__(64 * kSectionsPerWg) void enc_reverse_kernel(EncIma
   bool modular;
   if (!LossyStream(im, st, &tok, &n, &modular)) return;
   if (modular != (which == 0)) return;
-  const uint32_t state = ReversePass(tok, n, modular ? im.mcode : im.acode, sc, lane);
+  const uint32_t state = modular ? ReversePass<true>(tok, n, im.mcode, sc, lane) : ReversePass<false>(tok, n, im.acode, sc, lane);
   if (lane == 0) im.stream_state[st] = state;
 }
 
@@ -840,7 +850,7 @@ __global__ __launch_bounds__(64) void enc_global_alpha_kernel(EncImage im) {
   WaveWriter w;
   const int s = im.nlf + im.ng;
   w.Init(im.sec_bytes + (size_t)s * im.sec_cap, &sc, threadIdx.x);
-  EncodeStream(im.tok_alpha, (uint32_t)(im.w * im.h), im.mcode, w, &sc);
+  EncodeStream<false>(im.tok_alpha, (uint32_t)(im.w * im.h), im.mcode, w, &sc);
   const uint64_t bits = w.Finish();
   if (threadIdx.x == 0) im.sec_bits[s] = bits;
 }
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(64 * kSectionsPerWg) void enc_ll_sections_kernel(En
   WaveWriter w;
   w.Init(im.sec_bytes + (size_t)g * im.sec_cap, sc, lane);
   if (im.ng > 1) w.PutUniform(4, 3);   // group header; a single-group frame continues the GlobalModular stream of LfGlobal
-  EncodeStream(im.tok_ll + (size_t)g * kLlTokCap, (uint32_t)(gw * gh * im.ll_nch), im.mcode, w, sc);
+  EncodeStream<true>(im.tok_ll + (size_t)g * kLlTokCap, (uint32_t)(gw * gh * im.ll_nch), im.mcode, w, sc);
   const uint64_t bits = w.Finish();
   if (lane == 0) im.sec_bits[g] = bits;
 }

@@ -417,7 +417,11 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   hf_global.Bool(true);                      // default dequantisation matrices
   hf_global.Write(im.ng <= 1 ? 0 : 32 - __builtin_clz((unsigned)(im.ng - 1)), 0);   // one HF preset
   hf_global.U32(WV(0x5F), WV(0x13), WV(0), WB(kNumOrders), 0);                       // natural coefficient orders
-  BuildAndWriteCode(hist_ac.data(), kAcContexts, 64, {}, hf_global, acode);
+  {
+    const auto t0 = std::chrono::steady_clock::now();
+    BuildAndWriteCode(hist_ac.data(), kAcContexts, 64, {}, hf_global, acode);
+    if (clk.on) fprintf(stderr, "[enc] %-28s %8.2f ms (host only)\n", "HF code construction", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   clk.Lap("host: HF code (overlaps the LF recurrences)");
   // ---- 6. ANS coding of every section on the GPU (the Modular streams' recurrences have been running since their code was built)
   im.acode = UploadCode(A, acode);

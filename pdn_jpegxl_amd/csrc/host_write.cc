@@ -182,22 +182,26 @@ double XLog2X(uint64_t x) {
 
 struct Hist {
   std::vector<uint64_t> c;
+  std::vector<uint16_t> nz;   // the symbols that occur (most contexts use a handful of the alphabet)
   uint64_t total = 0;
+  double sumx = 0;   // sum c log2(c)
   double bits = 0;   // sum -c log2(c / total) = total log2(total) - sum c log2(c)
   void Finish() {
     total = 0;
-    for (auto v : c) total += v;
-    bits = XLog2X(total);
-    for (auto v : c) if (v) bits -= XLog2X(v);
+    sumx = 0;
+    nz.clear();
+    for (size_t i = 0; i < c.size(); i++) if (c[i]) { total += c[i]; sumx += XLog2X(c[i]); nz.push_back((uint16_t)i); }
+    bits = XLog2X(total) - sumx;
   }
 };
 
 // extra bits when both are coded with their merged distribution; nsym: symbols that occur at all (the tail of the alphabet is empty)
-double JoinCost(const Hist& a, const Hist& b, size_t nsym) {
+// (only the symbols of `a` change b's sum of c log2 c: the cost is linear in a's support, not in the alphabet)
+double JoinCost(const Hist& a, const Hist& b) {
   if (!a.total || !b.total) return 0;
-  double e = XLog2X(a.total + b.total);
-  for (size_t i = 0; i < nsym; i++) e -= XLog2X(a.c[i] + b.c[i]);
-  return e - a.bits - b.bits;
+  double merged = b.sumx;
+  for (uint16_t i : a.nz) merged += XLog2X(a.c[i] + b.c[i]) - XLog2X(b.c[i]);
+  return XLog2X(a.total + b.total) - merged - a.bits - b.bits;
 }
 
 }  // namespace
@@ -242,7 +246,6 @@ void BuildAndWriteCode(const uint32_t* hist, size_t num_ctx, int max_clusters, c
     for (size_t s = 0; s < A; s++) if (h[i].c[s]) max_sym = std::max<uint32_t>(max_sym, (uint32_t)s);
   }
   // ---- clustering: farthest-point seeds in join-cost distance, every context joins its cheapest seed
-  const size_t nsym = std::min<size_t>(A, (size_t)max_sym + 1);
   size_t budget = (size_t)std::max(1, std::min(max_clusters, 255)) - (any_pinned ? 1 : 0);
   if (budget < 1) budget = 1;
   std::vector<Hist> clusters;
@@ -254,29 +257,32 @@ void BuildAndWriteCode(const uint32_t* hist, size_t num_ctx, int max_clusters, c
     size_t first = used[0];
     for (size_t i : used) if (h[i].total > h[first].total) first = i;
     seeds.push_back(first);
+    // dmin / best: every context's cheapest seed so far - the distances of the seed search ARE the assignment (the first cheapest
+    // seed wins), so each (context, seed) pair is evaluated once
     std::vector<double> dmin(num_ctx, 1e300);
-    while (seeds.size() < budget) {
-      const size_t s = seeds.back();
+    std::vector<uint8_t> best(num_ctx, 0);
+    dmin[first] = -1.0;
+    for (;;) {
+      const size_t k = seeds.size() - 1, s = seeds[k];
       size_t far = used[0];
       double fard = -1;
       for (size_t i : used) {
-        dmin[i] = std::min(dmin[i], JoinCost(h[i], h[s], nsym));
+        if (i != s) {
+          const double d = JoinCost(h[i], h[s]);
+          if (d < dmin[i]) { dmin[i] = d; best[i] = (uint8_t)k; }
+        }
         if (dmin[i] > fard) { fard = dmin[i]; far = i; }
       }
-      if (fard <= 0) break;
+      if (seeds.size() >= budget || fard <= 0) break;
       seeds.push_back(far);
+      dmin[far] = -1.0;
+      best[far] = (uint8_t)(seeds.size() - 1);
     }
     clusters.assign(seeds.size(), Hist());
     for (auto& c : clusters) c.c.assign(A, 0);
     for (size_t i : used) {
-      size_t best = 0;
-      double bd = 1e300;
-      for (size_t k = 0; k < seeds.size(); k++) {
-        const double d = i == seeds[k] ? -1.0 : JoinCost(h[i], h[seeds[k]], nsym);
-        if (d < bd) { bd = d; best = k; }
-      }
-      out.ctx_map[i] = (uint8_t)best;
-      for (size_t s = 0; s < A; s++) clusters[best].c[s] += h[i].c[s];
+      out.ctx_map[i] = best[i];
+      for (uint16_t s : h[i].nz) clusters[best[i]].c[s] += h[i].c[s];
     }
   }
   if (any_pinned) {

@@ -517,8 +517,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.alpha = ws.Take((size_t)f.xsize * f.ysize * OutBytesPerSample(f));
     l.lf_end = ws.Take(8);
     if (f.tree_uses_wp) { l.wp_lf = ws.Take((size_t)f.nlf * kWpLfInts * 4); l.wp_grp = ws.Take((size_t)f.ng * 10 * (kGroupDim + 2) * 4); }
-    total_lf += f.nlf;
-    total_groups += f.ng * f.num_passes;
+    {
+      // sections this call decodes (a band: its group rows + one each side, the LF groups they touch): what the launch shapes go by
+      int b0 = 0, b1 = (int)f.yg;
+      if (band_rows > 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
+      const int g0 = std::max(0, b0 - 1), g1 = std::min<int>((int)f.yg, b1 + 1);
+      total_lf += ((g1 + 7) / 8 - g0 / 8) * (int)f.xlf;
+      total_groups += (g1 - g0) * (int)f.xg * (int)f.num_passes;
+    }
   }
   // The float planes between reconstruction and the loop filters (24 B/px) are only alive while a frame is in the pixel stages:
   // frames go through those stages in chunks that share kPixelChunk sets of planes, so the batch size is bounded by the
@@ -546,6 +552,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // Lane mapping of the HF kernel: one wavefront per section while every workgroup of the launch can be resident at once
   // (the kernel is latency-bound, a second round of workgroups doubles its time); otherwise pack more sections per wavefront.
   int lane_stride = 64;
+  int hf_wg_capacity = 256 * 8;   // workgroups of the HF kernel that can be resident at once (by the LDS of the widest tables)
   if (lane_stride_override > 0) lane_stride = lane_stride_override;
   else {
     size_t lds_est = 0;
@@ -554,6 +561,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
         lds_est = std::max(lds_est, 8 + 8 * frames[i].acode.alias.size() + 4 * frames[i].acode.cfg.size() + frames[i].acode.ctx_map.size() + 64 + 4 * (96 + 64 + 128));
     const int wg_per_cu = lds_est ? (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_est)) : 8;
     const int capacity = 256 * wg_per_cu;   // resident 256-thread workgroups on the chip
+    hf_wg_capacity = capacity;
     while (lane_stride > 1 && (total_groups + (256 / lane_stride) - 1) / (256 / lane_stride) > capacity) lane_stride >>= 1;
     // measured (MI355X, 4K frames, batch 384): once a batch holds thousands of sections, 32 sections per wavefront
     // (half-filled wavefronts, five per image instead of three) is the best trade between instruction efficiency and wavefronts
@@ -571,6 +579,13 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const int per_wave = 64 / lane_stride;
     const int need = (max_ng + per_wave - 1) / per_wave;
     if (need > 4 && lane_stride <= 8) hf_waves = std::min(8, need);
+    if (lane_stride == 64 && !getenv("JXLHIP_HF_WAVES8")) {
+      // One section per wavefront: its token loop runs on the scalar unit, and a CU has ONE scalar unit - eight such wavefronts in
+      // a workgroup share it (measured: hf_decode of one 4K frame 12.5 ms with 17 workgroups of 8 wavefronts).  Spread the sections
+      // over as many workgroups as can be resident at once, one wavefront each if they all fit.
+      hf_waves = 1;
+      while (hf_waves < 8 && (total_groups + hf_waves - 1) / hf_waves > hf_wg_capacity) hf_waves *= 2;
+    }
   }
   const int per_wg = hf_waves * (64 / lane_stride);
   // Sections per workgroup, per image: the HF kernel's LDS is the image's code tables (30 .. 60 KB: they double with the alias-table
@@ -611,7 +626,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   else {
     int alpha_sections = 0;
     for (int i = 0; i < n; i++)
-      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 && frames[i].alpha_index >= 0) alpha_sections += frames[i].ng;
+      if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 && frames[i].alpha_index >= 0) {
+        int b0 = 0, b1 = (int)frames[i].yg;   // a band decodes the alpha of its own group rows only
+        if (band_rows > 0) { b0 = std::min<int>(band_first_row, b1); b1 = std::min<int>(b0 + band_rows, b1); }
+        alpha_sections += (b1 - b0) * (int)frames[i].xg;
+      }
     while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
     if (alpha_sections >= 8192) alpha_stride = 2;   // measured: alpha_ans 27.8 ms (stride 1) / 22.5 (2) / 26.4 (4) at batch 384
     if (const char* e = getenv("JXLHIP_ALPHA_STRIDE")) alpha_stride = atoi(e);   // experiment knob

@@ -391,6 +391,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   };
   struct PerImg {
     std::vector<PassLayout> extra;
+    size_t m_direct = 0;   // + 1 when present
     size_t sec_off, sec_size, tree, m_cmap, m_cfg, m_alias, a_cmap, a_cfg, a_alias, order[kNumOrders][3], cs;
     size_t m_pfx[3] = {}, a_pfx[3] = {};           // prefix codes: counts, symbol offsets, sorted symbols
     size_t lz_lf = 0, lz_grp = 0, lz_hf = 0, lz_mod = 0;   // LZ77 windows (+1; 0: none)
@@ -409,18 +410,25 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // 256 columns); with the weighted predictor its per-sample state goes to LDS as well, which limits a workgroup to 8 sections
   int mod_lanes = 64, mod_rb = 0, mod_wp_lds = 0;
   size_t total_mod_sections = 0;
-  int max_mod_clusters = 0;
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok || frames[i].encoding != 1) continue;
     if (!frames[i].tree_row_static && frames[i].group_dim <= 256) mod_rb = 256;
     if (frames[i].tree_uses_wp && frames[i].group_dim <= 256) { mod_wp_lds = 1; mod_lanes = 8; }
     total_mod_sections += frames[i].single ? 1 : 1 + (size_t)frames[i].nlf + frames[i].ng;
-    max_mod_clusters = std::max<int>(max_mod_clusters, (int)frames[i].mcode.cfg.size());
   }
   if (!mod_rb) { mod_wp_lds = 0; mod_lanes = 64; }
   // few sections (one frame, a small batch): one section per wavefront - no divergence between sections, and row-static channels
   // decode on the scalar unit from per-residue tables (see the LF launch below)
   if (total_mod_sections <= 512 && !getenv("JXLHIP_MOD_LANES64")) mod_lanes = 1;
+  // Small launches get the Modular code's per-residue tables (the alias tables spelled out for each of the 4096 state residues,
+  // 16 KB per cluster, codes of up to 8 clusters): one-section wavefronts read them through the scalar cache (RowScalar).  Measured
+  // against a copy in LDS (one 4K frame): lf_ans 20.2 -> 18.8 ms, alpha_ans 5.7 -> 5.1 ms, and no LDS spent on them.
+  bool global_direct = false;
+  if (!getenv("JXLHIP_NO_DIRECT")) {
+    int pre_lf = 0;
+    for (int i = 0; i < n; i++) if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) pre_lf += (int)frames[i].nlf;
+    global_direct = n <= 64 && pre_lf <= 1024 && total_mod_sections <= 512;
+  }
   size_t chunk_pix = 0;   // padded pixels of the largest VarDCT frame of the batch
   for (int i = 0; i < n; i++) {
     if (parse_status[i] != DecoderStatus_Ok) continue;
@@ -433,6 +441,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.m_cmap = blob.Take(f.mcode.ctx_map.size());
     l.m_cfg = blob.Take(4 * f.mcode.cfg.size());
     l.m_alias = blob.Take(8 * f.mcode.alias.size());
+    if (global_direct && !f.mcode.use_prefix && !f.mcode.lz77 && f.mcode.num_hist <= 8) l.m_direct = blob.Take((size_t)f.mcode.num_hist << 14) + 1;
     auto pfx_layout = [&](const HostCode& hc, size_t* o) {
       if (!hc.use_prefix) return;
       size_t total = 0;
@@ -668,7 +677,6 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   imgs.assign(n + n_extra, DevImage());
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
-  int max_mclusters = 0;   // most clusters of any frame's Modular code (sizes the direct tables of one-section wavefronts)
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
   bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
@@ -755,8 +763,22 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       dc.num_ctx = (uint32_t)hc.ctx_map.size();
       dc.num_clusters = hc.num_hist;
       dc.log_alpha = hc.log_alpha;
+      dc.direct = nullptr;
     };
     code(f.mcode, l.m_cmap, l.m_cfg, l.m_alias, d.mcode, l.m_pfx);
+    if (l.m_direct) {   // the alias tables spelled out per state residue
+      uint32_t* dt = (uint32_t*)(h_blob + l.m_direct - 1);
+      const uint32_t la = f.mcode.log_alpha, le = 12 - la;
+      for (uint32_t r = 0; r < (f.mcode.num_hist << 12); r++) {
+        const uint32_t cl = r >> 12, res = r & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
+        const uint64_t e = f.mcode.alias[(cl << la) + i];
+        const uint32_t x = (uint32_t)e, y = (uint32_t)(e >> 32);
+        const bool g = pos >= (x & 0xFF);
+        const uint32_t sym = g ? ((x >> 8) & 0xFF) : i, o = g ? (y & 0xFFFF) + pos : pos, freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
+        dt[r] = ((freq - 1) & 0xFFF) | ((o & 0xFFF) << 12) | (sym << 24);
+      }
+      d.mcode.direct = (const uint32_t*)(d_blob + l.m_direct - 1);
+    }
     d.sec_off = (const uint64_t*)(d_blob + l.sec_off);
     d.sec_size = (const uint32_t*)(d_blob + l.sec_size);
     d.tree = (const DevTreeNode*)(d_blob + l.tree);
@@ -940,7 +962,6 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     auto code_lds = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
     lds_lf = std::max(lds_lf, (size_t)lf_per_wave * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
     lds_alpha = std::max(lds_alpha, (size_t)per_alpha_wg * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + code_lds(f.mcode));
-    max_mclusters = std::max<int>(max_mclusters, (int)f.mcode.cfg.size());
     max_groups = std::max<int>(max_groups, (int)f.ng);
     // LF groups that intersect the decoded group rows (8 group rows per LF group row); HF groups of the decoded rows; alpha of the band
     const uint32_t lfy0 = (uint32_t)d.dec_gy0 / 8, lfy1 = ((uint32_t)d.dec_gy1 + 7) / 8;
@@ -1028,16 +1049,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (!(skip_stages & 1)) HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
-  // wavefronts that decode one section get per-residue tables of the Modular code (16 KB per cluster) when they fit
-  // (measured at batch 384: LF sections as four such wavefronts per workgroup sharing the tables - 135.7 ms per batch against 125.1
-  // with four lanes of one wavefront: large batches keep the lane layout, the scalar path is for small ones)
-  auto direct_room = [&](size_t lds, int per_wave) {
-    if (per_wave != 1 || lds > kLdsMax || getenv("JXLHIP_NO_DIRECT")) return 0;
-    return std::min<int>(max_mclusters, (int)((kLdsMax - lds) >> 14));
-  };
-  const int direct_lf = direct_room(lds_lf + 16, lf_per_wave), direct_alpha = direct_room(lds_alpha + 16, per_alpha_wg);
-  if (direct_lf) lds_lf += 16 + ((size_t)direct_lf << 14);
-  if (direct_alpha) lds_alpha += 16 + ((size_t)direct_alpha << 14);
+  // wavefronts that decode one section run their row loops on the scalar unit from the per-residue tables built above
+  // (measured at batch 384: LF sections as four such wavefronts per workgroup - 135.7 ms per batch against 125.1 with four lanes of
+  // one wavefront: large batches keep the lane layout, the scalar path is for small ones)
+  const int direct_lf = global_direct && lf_per_wave == 1, direct_alpha = global_direct && per_alpha_wg == 1;
   if (!(skip_stages & 1)) {
   LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, direct_lf, s_lf);
   Mark("lf_ans", s_lf, 0);
@@ -1089,9 +1104,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload
     if (s_lf != stream) { HIP_OK(hipEventRecord(S.lf_done, s_lf)); HIP_OK(hipStreamWaitEvent(stream, S.lf_done, 0)); }
-    int direct_mod = 0;
-    if (mod_lanes == 1 && lds_mod + 16 <= kLdsMax && !getenv("JXLHIP_NO_DIRECT")) direct_mod = std::min<int>(max_mod_clusters, (int)((kLdsMax - lds_mod - 16) >> 14));
-    if (direct_mod) lds_mod += 16 + ((size_t)direct_mod << 14);
+    const int direct_mod = global_direct && mod_lanes == 1;
     LaunchModularAns(d_imgs, n, (const SectionTask*)(d_blob + off_mod_tasks), nmod_t, lds_mod <= kLdsMax ? lds_mod : 0, max_mod_groups,
                      max_mod_coded, mod_lanes, mod_rb, mod_wp_lds, direct_mod, stream);
     for (auto& op : mod_ops) {

@@ -51,6 +51,9 @@ struct DevCode {
   const uint32_t* pfx_off;
   // LZ77: symbols >= lz_min_symbol start a copy; its length uses lz_len_cfg (packed like cfg), its distance the cluster of the last context
   uint32_t lz_min_symbol, lz_min_length, lz_len_cfg, lz_dist_cluster;
+  // ANS codes of small launches: per cluster 4096 entries, one per state residue (freq - 1 | offset << 12 | symbol << 24), read by
+  // one-section wavefronts through the scalar cache; null when not built
+  const uint32_t* direct;
 };
 
 // Outcome of phase A (one lane per section) for one Modular channel; phase B (a wavefront per channel) finishes it.

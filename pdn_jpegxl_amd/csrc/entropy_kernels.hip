@@ -169,7 +169,7 @@ struct CodeTab {
   typename AS<kLds>::U8 cmap;
   typename AS<kLds>::U32 cfg;     // split | msb << 4 | lsb << 8 | degenerate << 12 | symbol << 16
   typename AS<kLds>::U64 alias;
-  typename AS<kLds>::U32 direct;  // per cluster 4096 entries, one per state residue: freq - 1 | offset << 12 | symbol << 24 (or null)
+  const uint32_t* direct;   // DevCode::direct when this wavefront decodes one section (per-residue tables, read by scalar loads), else null
   uint32_t log_alpha;
   uint32_t slow;        // DevCode::slow (uniform over the workgroup: one image's code)
   const DevCode* dc;    // the prefix / LZ77 parameters stay in global memory
@@ -336,28 +336,13 @@ __device__ __forceinline__ uint32_t AnsGet(Bits& b, uint32_t& state, const CodeT
 
 // Cooperative copy of a code's tables into LDS; returns the carved end offset.
 __device__ __forceinline__ size_t StageCode(JXL_LDS uint8_t* smem, size_t off, const DevCode& dc, CodeTab<true>& t, int tid, int nt,
-                                            int direct_clusters = 0) {
+                                            bool one_section = false) {
   const uint32_t na = (dc.slow & 1) ? 0u : dc.num_clusters << dc.log_alpha;   // prefix codes have no alias tables
-  t.direct = nullptr;
-  if (direct_clusters > 0 && !dc.slow && dc.num_clusters <= (uint32_t)direct_clusters) {
-    // The alias tables spelled out per state residue, for wavefronts that decode ONE section: such a wavefront issues an instruction
-    // every four to five cycles whatever unit executes it, so its time per token is its instruction count, and the alias
-    // arithmetic (bucket, cutoff compare, three selects) is a third of the token.  16 KB per cluster, built by all 64 lanes.
-    off = (off + 15) & ~(size_t)15;
-    JXL_LDS uint32_t* sd = (JXL_LDS uint32_t*)(smem + off); off += (size_t)dc.num_clusters << 14;
-    const uint32_t la = dc.log_alpha, le = 12 - la;
-    for (uint32_t r = tid; r < (dc.num_clusters << 12); r += nt) {
-      const uint32_t cl = r >> 12, res = r & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
-      const uint64_t e = dc.alias[(cl << la) + i];
-      const uint32_t x = (uint32_t)e, y = (uint32_t)(e >> 32);
-      const bool g = pos >= (x & 0xFF);
-      const uint32_t sym = g ? ((x >> 8) & 0xFF) : i;
-      const uint32_t o = g ? (y & 0xFFFF) + pos : pos;
-      const uint32_t freq = g ? ((x >> 16) ^ (y >> 16)) : (x >> 16);
-      sd[r] = ((freq - 1) & 0xFFF) | ((o & 0xFFF) << 12) | (sym << 24);
-    }
-    t.direct = sd;
-  }
+  // One-section wavefronts run their row loops on the scalar unit (RowScalar) and read the code's per-residue tables - the alias
+  // tables spelled out for each of the 4096 state residues, built by the host for small launches - through the scalar cache: such a
+  // wavefront issues an instruction every four to five cycles whatever unit executes it, so its time per token is its instruction
+  // count, and the alias arithmetic (bucket, cutoff compare, three selects) is a third of the token.
+  t.direct = (one_section && !dc.slow) ? dc.direct : nullptr;
   off = (off + 7) & ~(size_t)7;
   JXL_LDS uint64_t* sa = (JXL_LDS uint64_t*)(smem + off); off += (size_t)na * 8;
   JXL_LDS uint32_t* sc = (JXL_LDS uint32_t*)(smem + off); off += (size_t)dc.num_clusters * 4;
@@ -689,8 +674,9 @@ __device__ int ClassifyChannel(const CodeTab<kLds>& tab, typename AS<kLds>::Tree
 // token: sixteen tokens unrolled between top-ups (no loop or address arithmetic per token), the common leaf (multiplier 1, offset
 // 0, predictor applied in phase B) without the multiply / offset / West instructions.
 #define JXL_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
-template <bool kPlain>
-__device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, const JXL_LDS uint32_t* dt, uint32_t cfg, uint32_t mul, uint32_t off,
+typedef const __attribute__((address_space(4))) uint32_t* ConstU32;   // constant address space: uniform reads become scalar loads
+template <bool kPlain, class TabPtr>
+__device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, TabPtr dt, uint32_t cfg, uint32_t mul, uint32_t off,
                                           bool add_w, uint32_t W, uint32_t& first_out, JXL_GLB int32_t* row, int w) {
   uint32_t s_state = JXL_RFL(state), s_w = JXL_RFL(W), s_first = 0, s_rd = JXL_RFL(b.rd);
   uint64_t s_buf = ((uint64_t)JXL_RFL((uint32_t)(b.buf >> 32)) << 32) | JXL_RFL((uint32_t)b.buf);
@@ -796,10 +782,12 @@ __device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, 
     // sixteen tokens per top-up of the bit window; no per-token bookkeeping beyond the decode itself
     uint32_t first = 0;
     if constexpr (kLds) {
-      if (tab.direct) {   // one section per wavefront: the scalar-unit loop over the direct table of the row's cluster
-        const JXL_LDS uint32_t* const dt = tab.direct + (cl << 12);
-        if (mul == 1 && off == 0 && needs_n) RowScalar<true>(b, state, dt, cfg, 1u, 0u, false, W, first, row, w);
-        else RowScalar<false>(b, state, dt, cfg, mul, off, add_w, W, first, row, w);
+      if (tab.direct) {   // one section per wavefront: the scalar-unit loop, table entries by scalar loads
+        const uint64_t ga = (uint64_t)(uintptr_t)(tab.direct + (cl << 12));
+        const ConstU32 dt = (ConstU32)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ga));
+        if (mul == 1 && off == 0 && needs_n) RowScalar<true, ConstU32>(b, state, dt, cfg, 1u, 0u, false, W, first, row, w);
+        else RowScalar<false, ConstU32>(b, state, dt, cfg, mul, off, add_w, W, first, row, w);
         first_prev = first;
         continue;
       }
@@ -1003,14 +991,14 @@ struct ModTables {
 // Stages the MA tree + modular code of `im` (LDS variant) or points at them in global memory.
 template <bool kLds>
 __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem, size_t off, ModTables<kLds>& t, int tid, int nt,
-                                              int direct_clusters = 0) {
+                                              bool one_section = false) {
   if constexpr (kLds) {
     JXL_LDS uint8_t* lds = (JXL_LDS uint8_t*)smem;
     off = (off + 15) & ~(size_t)15;
     JXL_LDS I4* st = (JXL_LDS I4*)(lds + off); off += (size_t)im.tree_size * sizeof(DevTreeNode);
     for (int i = tid; i < im.tree_size; i += nt) st[i] = ((const I4*)im.tree)[i];
     t.tree = st;
-    StageCode(lds, off, im.mcode, t.tab, tid, nt, direct_clusters);
+    StageCode(lds, off, im.mcode, t.tab, tid, nt, one_section);
     __syncthreads();
   } else {
     GlobalCode(im.mcode, t.tab);
@@ -1024,14 +1012,14 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds>
-__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int direct_clusters) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   ModTables<kLds> mt;
   // `slots` lanes of the wavefront decode (the launch's sections per workgroup): the bit windows take slots * 128 B of LDS, not 8 KB -
   // LDS is what decides whether this kernel can share a CU with the HF decoder of the batch before
-  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 ? direct_clusters : 0);
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 && scalar_rows);
   const int lane = threadIdx.x;
   if (lane >= task.count || lane >= slots) return;
   const int g = task.first + lane;
@@ -1635,14 +1623,14 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds>
-__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int direct_clusters) {
+__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   if (!im.has_alpha || im.alpha_in_global) return;
   ModTables<kLds> mt;
   const int slots = 64 / lane_stride;
-  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 ? direct_clusters : 0);
+  LoadModTables<kLds>(im, smem, (size_t)slots * kRingWords * 4, mt, threadIdx.x, 64, slots == 1 && scalar_rows);
   const int lane = threadIdx.x;
   if (lane >= slots || lane >= task.count) return;
   const int g = task.first + lane;
@@ -1757,7 +1745,7 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // Phase A: one lane per section.  A frame with a single TOC entry is one bit stream: its lane walks global, LF group and pass
 // group one after the other.
 template <bool kLds>
-__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int direct_clusters) {
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
@@ -1767,7 +1755,7 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
   const size_t wp_ints = (size_t)10 * (rb_width + 2);
   const size_t off_tab = off_wp + (wp_lds ? (size_t)lanes * wp_ints * 4 : 0);
   ModTables<kLds> mt;
-  LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64, lanes == 1 ? direct_clusters : 0);
+  LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64, lanes == 1 && scalar_rows);
   const int lane = threadIdx.x;
   if (lane >= task.count || lane >= lanes) return;
   RowBuf<kLds> rows;
@@ -1967,11 +1955,11 @@ static void RaiseLds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int direct_clusters, hipStream_t s) {
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, hipStream_t s) {
   if (ntasks <= 0) return;   // slots: sections per workgroup (lanes that decode); lds_bytes: their bit windows + the tables (0: tables stay global)
   if (lds_bytes) {
     RaiseLds((const void*)lf_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots, direct_clusters);
+    hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots, scalar_rows);
   } else {
     hipLaunchKernelGGL(lf_ans_kernel<false>, dim3(ntasks), dim3(64), (size_t)slots * kRingWords * 4, s, imgs, tasks, slots, 0);
   }
@@ -2002,22 +1990,22 @@ void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int
   }
 }
 
-void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int direct_clusters, hipStream_t s) {
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, hipStream_t s) {
   if (nwg <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)alpha_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride, direct_clusters);
+    hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride, scalar_rows);
   } else {
     hipLaunchKernelGGL(alpha_ans_kernel<false>, dim3(nwg), dim3(64), (size_t)(64 / lane_stride) * kRingWords * 4, s, imgs, tasks, lane_stride, 0);
   }
 }
 
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      int lanes, int rb_width, int wp_lds, int direct_clusters, hipStream_t s) {
+                      int lanes, int rb_width, int wp_lds, int scalar_rows, hipStream_t s) {
   if (ntasks <= 0) return;
   if (lds_bytes) {
     RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
-    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds, direct_clusters);
+    hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds, scalar_rows);
   } else {
     const size_t lds = (size_t)64 * kRingWords * 4 + (size_t)lanes * rb_width * 4 + (wp_lds ? (size_t)lanes * 10 * (rb_width + 2) * 4 : 0);
     RaiseLds((const void*)modular_ans_kernel<false>, lds);

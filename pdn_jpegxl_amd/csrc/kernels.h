@@ -7,20 +7,20 @@ namespace jxlhip {
 
 // entropy_kernels.hip (lds_bytes == 0 selects the variant that keeps its tables in global memory)
 // LF groups: phase A (ANS, one lane per LF group, one wavefront per image chunk) and phase B (one workgroup per LF group)
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int direct_clusters, hipStream_t s);
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, hipStream_t s);
 void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int ring_words, size_t lds_bytes,
                     size_t lane_bytes, hipStream_t s);
-void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int direct_clusters, hipStream_t s);
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical
 // unsqueeze of planes a (average), b (residual) into c); clamp + interleave
 // lanes: sections per workgroup; rb_width > 0: previous-row buffers (and, with wp_lds, the weighted-predictor state) of the generic
 // lane path live in LDS
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
-                      int lanes, int rb_width, int wp_lds, int direct_clusters, hipStream_t s);
+                      int lanes, int rb_width, int wp_lds, int scalar_rows, hipStream_t s);
 void LaunchModularOp(int kind, int32_t* a, int32_t* b, int32_t* c, int aw, int ah, int rw, int rh, int type, hipStream_t s);
 // inverse Palette: out[k][i] = palette[k * nb_colors + index[i]] for the w x h samples of the index channel; indices outside the
 // stored palette (implicit / delta colours) raise the image's error flag

@@ -24,13 +24,16 @@ print("encode %dx%d: %.2f s, %.1f MB" % (N, N, time.perf_counter() - t0, len(dat
 del bgra
 dec = api.Decoder(0)
 whole = torch.empty(N * N * 4, dtype=torch.uint8, device="cuda")
-for _ in range(2):
+tws = []
+for _ in range(5):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     assert dec.decode_batch([data], [whole.data_ptr()]) == [0]
     torch.cuda.synchronize()
-    tw = time.perf_counter() - t0
-print("whole frame on one GPU: %.1f ms (%.0f MP/s)" % (tw * 1e3, N * N / tw / 1e6), flush=True)
+    tws.append(time.perf_counter() - t0)
+tw = min(tws[1:])
+print("whole frame on one GPU: %.1f ms (%.0f MP/s); every call: %s ms; stages of the last: %s"
+      % (tw * 1e3, N * N / tw / 1e6, [round(t * 1e3, 1) for t in tws], {k: round(v, 1) for k, v in dec.stage_times().items()}), flush=True)
 ref = whole.view(N, N, 4)
 world = 8
 times = []

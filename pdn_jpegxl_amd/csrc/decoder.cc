@@ -640,7 +640,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
         if (band_rows > 0) { b0 = std::min<int>(band_first_row, b1); b1 = std::min<int>(b0 + band_rows, b1); }
         alpha_sections += (b1 - b0) * (int)frames[i].xg;
       }
-    while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
+    // Two good shapes and a bad middle (measured, 4K frames): one section per wavefront on the scalar unit (5 ms for 135 sections,
+    // degrading gently while a CU holds a dozen such wavefronts) and 32 sections per wavefront on the vector unit (12 ms for 8640
+    // sections); 2 ... 16 sections per wavefront pay the vector chain for a few lanes (21 ms for 2160 sections at 2 per wavefront).
+    if (global_direct && !getenv("JXLHIP_ALPHA_OLD_SHAPES")) alpha_stride = alpha_sections > 3072 ? 2 : 64;
+    else while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
     if (alpha_sections >= 8192) alpha_stride = 2;   // measured: alpha_ans 27.8 ms (stride 1) / 22.5 (2) / 26.4 (4) at batch 384
     if (const char* e = getenv("JXLHIP_ALPHA_STRIDE")) alpha_stride = atoi(e);   // experiment knob
   }

@@ -563,10 +563,7 @@ namespace {
 // The bits are then laid out front to back by all lanes at once: a wavefront prefix sum of the token lengths gives every lane its
 // bit offset, the lanes OR their bits into an LDS staging window, complete words go out coalesced.
 struct WaveScratch {
-  uint32_t freq[64];
-  float rcp[64];
-  uint32_t rbase[64];
-  uint32_t flush[64];
+  uint32_t flush[64];      // reverse pass: the flush word of each of the 64 tokens in flight
   uint32_t stage[128];   // bits [32 * wbase, ...) of the section, not yet written out
 };
 

@@ -310,3 +310,21 @@ def test_block_contexts_from_lf_and_quant_field_thresholds(gpu_decoder, oracle, 
     check_pixels(gpu_decode(gpu_decoder, [data])[0], oracle.decode(oracle.encode(img, **extra)).pixels)
     small = synth(210, 150, 96)
     run_case(gpu_decoder, oracle, small, lf_contexts=True)
+
+
+def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle, monkeypatch):
+    """One-section wavefronts decode on the scalar unit (per-residue tables through the scalar cache, counted HF token loop); many
+    sections per wavefront use the vector loops.  Same streams, both shapes of launch: the outputs must be byte-identical.
+    Covers a lossy RGBA frame (LF, HF, alpha rows), a product-encoded lossless frame and an oracle lossless frame with West rows."""
+    img = synth(700, 520, 11)
+    streams = [oracle.encode(img, distance=1.0),
+               api.save_image(np.ascontiguousarray(img[..., [2, 1, 0, 3]]), lossless=True),
+               oracle.encode(np.ascontiguousarray(img[..., :3]), lossless=True, lossless_tree=0, lossless_predictor=1)]
+    scalar = [gpu_decode(gpu_decoder, [s])[0] for s in streams]
+    monkeypatch.setenv("JXLHIP_NO_DIRECT", "1")      # no per-residue tables: the vector row loops on one lane
+    vector1 = [gpu_decode(gpu_decoder, [s])[0] for s in streams]
+    monkeypatch.setenv("JXLHIP_MOD_LANES64", "1")    # Modular sections 64 to a wavefront
+    vector2 = [gpu_decode(gpu_decoder, [s], lane_stride=2)[0] for s in streams]   # HF / alpha sections 32 to a wavefront
+    for a, b, c in zip(scalar, vector1, vector2):
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, c)

@@ -699,7 +699,7 @@ __device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, TabPtr d
     }
     const uint32_t sym = e >> 24;
     uint32_t u = sym;
-    if (sym >= split) {
+    if (__builtin_expect(sym >= split, 0)) {   // out of line: a taken scalar branch costs far more than a scalar instruction here
       const uint32_t nb = se - (msb + lsb) + ((sym - split) >> (msb + lsb)), nbr = nb > 32 ? 32 : nb;
       word();
       const uint32_t bits = (uint32_t)(s_buf & (((uint64_t)1 << nbr) - 1));
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
           const uint32_t res = s_state & 0xFFF, i = res >> le, pos = res & ((1u << le) - 1);
           const uint64_t e = tab.alias[(cl << la) | i];
           uint32_t c = cfg_uni;
-          if (!cfg_is_uni) c = JXL_RFL(tab.cfg[cl]);
+          if (__builtin_expect(!cfg_is_uni, 0)) c = JXL_RFL(tab.cfg[cl]);
           const uint32_t x = JXL_RFL((uint32_t)e), y = JXL_RFL((uint32_t)(e >> 32));
           const bool gt = pos >= (x & 0xFF);
           const uint32_t sym = gt ? ((x >> 8) & 0xFF) : i;
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
           }
           uint32_t u = sym;
           const uint32_t se = c & 0xF, split = 1u << se;
-          if (sym >= split) {
+          if (__builtin_expect(sym >= split, 0)) {
             const uint32_t msb = (c >> 4) & 0xF, lsb = (c >> 8) & 0xF;
             const uint32_t nb = se - (msb + lsb) + ((sym - split) >> (msb + lsb)), nbr = nb > 32 ? 32 : nb;
             if (s_n <= 32) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRing - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }

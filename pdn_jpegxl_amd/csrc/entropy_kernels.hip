@@ -686,13 +686,17 @@ __device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, TabPtr d
   const bool s_addw = JXL_RFL(add_w ? 1u : 0u) != 0;
   const int sw = (int)JXL_RFL(w);
   auto word = [&]() {
-    if (s_n <= 32) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRingWords - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }
+    if (__builtin_expect(s_n <= 32, 0)) { s_buf |= (uint64_t)JXL_RFL(b.ring[__umul24(s_rd & (kRingWords - 1), b.rs)]) << s_n; s_n += 32; s_rd++; }
   };
   auto token = [&](int x) {
     const uint32_t e = JXL_RFL(dt[s_state & 0xFFF]);
     const uint32_t hi = s_state >> 12;
-    s_state = (e & 0xFFF) * hi + hi + ((e >> 12) & 0xFFF);
-    if (s_state < 65536u) {
+    // freq * hi + offset with freq - 1 stored: (freq - 1) * hi + (hi + offset), the sum kept apart so that the chain from the table
+    // entry to the new state is and -> multiply -> add (left alone, the compiler forms freq first: one more dependent operation)
+    uint32_t t = hi + ((e >> 12) & 0xFFF);
+    asm volatile("" : "+s"(t));
+    s_state = (e & 0xFFF) * hi + t;
+    if (__builtin_expect(s_state < 65536u, 0)) {
       word();
       s_state = (s_state << 16) | ((uint32_t)s_buf & 0xFFFFu);
       s_buf >>= 16; s_n -= 16;

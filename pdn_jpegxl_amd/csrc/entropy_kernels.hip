@@ -1410,6 +1410,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   int ci = 3;
   uint32_t nzeros = 0, k = 0, prev = 0, histo = 0;
   bool want_nz = true;
+#ifdef JXLHIP_PROFILE_HF
+  const uint64_t pf_start = clock64();
+  uint64_t pf_scalar = 0, pf_period = 0, pf_tokens = 0, pf_entries = 0, pf_periods = 0;
+#endif
   // one-section wavefronts: do all clusters share one hybrid-integer configuration?  (then the token loop keeps it in a register)
   uint32_t cfg_uni = 0;
   bool cfg_is_uni = false;
@@ -1422,6 +1426,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   }
   while (!err) {
     if ((it & (kTop - 1)) == 0) {
+#ifdef JXLHIP_PROFILE_HF
+      const uint64_t pf_t0 = clock64();
+      pf_periods++;
+#endif
       b.TopUp();
       // descriptors the same way: a period starts at most kQ blocks, the queue holds 2 * kQ; what the previous period requested is
       // queued now, the next kQ are requested
@@ -1448,6 +1456,9 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
           for (int i = 0; i < kQ; i++) { dpend[i] = 0u; if ((uint32_t)i < dpend_n) dpend[i] = list[dfilled + i]; }
         }
       }
+#ifdef JXLHIP_PROFILE_HF
+      pf_period += clock64() - pf_t0;
+#endif
     }
     // Fast path: while every lane of the wavefront that is still decoding sits inside a run of coefficient tokens (always the
     // case with one section per wavefront, i.e. small batches), stay in a loop that holds nothing but the coefficient token:
@@ -1460,6 +1471,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
         // through the same door, and the recurrence state -> alias entry -> state runs on the scalar unit; only the LDS addresses and
         // the entry store touch vector registers.
 #define JXL_RFL(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#ifdef JXLHIP_PROFILE_HF
+        const uint64_t pf_t1 = clock64();
+        pf_entries++;
+#endif
         // A lone wavefront issues one instruction every four cycles or so, and every LDS lookup on the chain adds ~80: the loop is
         // written for few instructions and few dependent lookups - the tokens a period or the block still allows are counted down
         // (no per-token stop conditions), the non-zero-count bucket is looked up again only after a non-zero coefficient, the range
@@ -1524,6 +1539,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
           }
         } while (cnt);
         s_it += cnt0 - cnt;
+#ifdef JXLHIP_PROFILE_HF
+        pf_scalar += clock64() - pf_t1;
+        pf_tokens += cnt0 - cnt;
+#endif
         uint32_t s_err = s_rng > 0xFFFFu ? (uint32_t)kErrRange : 0u;
         if (s_nz != 0 && s_k >= s_size) s_err |= kErrBitstream;
 #undef JXL_RFL
@@ -1621,6 +1640,12 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const uint64_t used = b.Consumed();
   if (!err && sec_bits + used > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
   im.grp_bitpos[g] = err ? ~(uint64_t)0 : sec_bits + used;
+#ifdef JXLHIP_PROFILE_HF
+  if (per_wave == 1)
+    printf("[hfprof] g %d total %llu scalar-loop %llu (%llu entries, %llu tokens) period %llu (%llu periods) blocks %u\n", g,
+           (unsigned long long)(clock64() - pf_start), (unsigned long long)pf_scalar, (unsigned long long)pf_entries,
+           (unsigned long long)pf_tokens, (unsigned long long)pf_period, (unsigned long long)pf_periods, nblk);
+#endif
   if (err) SetError(im, err, 3, g);
 }
 

@@ -1412,7 +1412,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   bool want_nz = true;
 #ifdef JXLHIP_PROFILE_HF
   const uint64_t pf_start = clock64();
-  uint64_t pf_scalar = 0, pf_period = 0, pf_tokens = 0, pf_entries = 0, pf_periods = 0;
+  uint64_t pf_scalar = 0, pf_period = 0, pf_tokens = 0, pf_entries = 0, pf_periods = 0, pf_general = 0, pf_general_n = 0;
 #endif
   // one-section wavefronts: do all clusters share one hybrid-integer configuration?  (then the token loop keeps it in a register)
   uint32_t cfg_uni = 0;
@@ -1573,6 +1573,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       }
       continue;
     }
+#ifdef JXLHIP_PROFILE_HF
+    const uint64_t pf_t2 = clock64();
+    pf_general_n++;
+#endif
     if (want_nz && ci >= 3) {
       if (bi >= nblk) break;
       const uint32_t d = dq[__umul24(bi & dqmask, nslots)];
@@ -1635,6 +1639,9 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
       }
       if (++k >= size && nzeros != 0) { err |= kErrBitstream; break; }
     }
+#ifdef JXLHIP_PROFILE_HF
+    pf_general += clock64() - pf_t2;
+#endif
   }
   if (!err && (state != 0x130000u || b.slow_err)) err |= kErrBitstream;
   const uint64_t used = b.Consumed();
@@ -1642,9 +1649,10 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   im.grp_bitpos[g] = err ? ~(uint64_t)0 : sec_bits + used;
 #ifdef JXLHIP_PROFILE_HF
   if (per_wave == 1)
-    printf("[hfprof] g %d total %llu scalar-loop %llu (%llu entries, %llu tokens) period %llu (%llu periods) blocks %u\n", g,
+    printf("[hfprof] g %d total %llu scalar-loop %llu (%llu entries, %llu tokens) period %llu (%llu periods) blocks %u general %llu (%llu iterations)\n", g,
            (unsigned long long)(clock64() - pf_start), (unsigned long long)pf_scalar, (unsigned long long)pf_entries,
-           (unsigned long long)pf_tokens, (unsigned long long)pf_period, (unsigned long long)pf_periods, nblk);
+           (unsigned long long)pf_tokens, (unsigned long long)pf_period, (unsigned long long)pf_periods, nblk,
+           (unsigned long long)pf_general, (unsigned long long)pf_general_n);
 #endif
   if (err) SetError(im, err, 3, g);
 }

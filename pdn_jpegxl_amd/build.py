@@ -50,8 +50,14 @@ def build(force=False, verbose=False):
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-x", "hip", "-c", s, "-o", o] + os.environ.get("JXLHIP_EXTRA_CFLAGS", "").split()
+        # an object built with other extra flags (e.g. -DJXLHIP_PROFILE_HF) is stale even when its sources have not changed
+        extra = os.environ.get("JXLHIP_EXTRA_CFLAGS", "")
+        flagfile = o + ".flags"
+        old_extra = open(flagfile).read() if os.path.exists(flagfile) else ""
+        if force or extra != old_extra or _stale(o, [s] + hdrs):
+            with open(flagfile, "w") as ff:
+                ff.write(extra)
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-x", "hip", "-c", s, "-o", o] + extra.split()
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -93,7 +93,7 @@ void jxo_last_encode_token_counts(uint64_t out[4]) { GetLastEncodeTokenCounts(ou
 static thread_local std::vector<uint8_t> g_next_icc;
 static thread_local bool g_next_cmyk = false;
 static thread_local int g_next_frames = 1;
-static thread_local uint32_t g_next_flags = 0;   // 1: explicit (custom) dequantisation tables; 2: prefix codes; 4: LZ77; 8 / 16: two / three passes; 32: custom coefficient orders; 64: block contexts from LF / quant-field thresholds
+static thread_local uint32_t g_next_flags = 0;   // 1: explicit (custom) dequantisation tables; 2: prefix codes; 4: LZ77; 8 / 16: two / three passes; 32: custom coefficient orders; 64: block contexts from LF / quant-field thresholds; 128: palette; 256: some DCT8 blocks labelled AFV (refusal tests); 512: alpha signalled as premultiplied
 void jxo_set_next_flags(uint32_t flags) { g_next_flags = flags; }
 void jxo_set_next_animation(int frames) { g_next_frames = frames; }
 void jxo_set_next_icc(const uint8_t* icc, size_t size, int cmyk) {
@@ -140,6 +140,8 @@ JxoBytes* jxo_encode(const uint8_t* px, uint32_t w, uint32_t h, int32_t nch, con
     p.custom_orders = (g_next_flags & 32) != 0;
     p.lf_contexts = (g_next_flags & 64) != 0;
     p.palette = (g_next_flags & 128) != 0;
+    p.mislabel_afv = (g_next_flags & 256) != 0;
+    p.premultiplied_alpha = (g_next_flags & 512) != 0;
     p.num_passes = (g_next_flags & 16) ? 3 : ((g_next_flags & 8) ? 2 : 1);
     const uint32_t g_next_flags_entropy = g_next_flags;
     g_next_flags = 0;

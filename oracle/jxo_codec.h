@@ -80,6 +80,9 @@ struct EncodeParams {
   bool custom_quant_tables = false;   // lossy: every dequantisation table written explicitly (parameters scaled per table by `seed`)
   int animation_frames = 1;     // > 1: an animation; frame k > 0 shows the picture rotated by 180 degrees / inverted (any decoder
                                 // that returns something other than the first frame is caught)
+  bool mislabel_afv = false;    // lossy, REFUSAL TESTS ONLY: some 8x8 DCT blocks are written to the block-metadata stream as AFV0..AFV3 (the
+                                // coefficients stay those of the 8x8 DCT, so the stream is not a meaningful picture): a decoder without AFV must refuse it
+  bool premultiplied_alpha = false;   // the alpha channel is signalled as associated; the colour samples handed in are ALREADY premultiplied
   bool cmyk = false;            // lossless only: nch 4 / 5 = C, M, Y, K [, A] as STORED (0 = full ink); K goes to a black extra channel
 };
 

@@ -645,6 +645,23 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     const size_t i = ((size_t)y * w + x) * nch + c;
     for (int k = 0; k < bpo; k++) out.pixels[(size_t)bpo * i + k] = (uint8_t)(v >> (8 * k));
   };
+  // Premultiplied (associated) alpha: the reference asks its library for un-premultiplied output (Decoder/JxlDecoder.cpp:233).  The library
+  // divides the ENCODED colour samples (after the transfer function, as floats) by max(alpha, 2^-26) where it writes the output
+  // samples  [spec, recalled; no external vector: parity unpinned].  unpremul(y, x): the multiplier, 1 when alpha is not associated.
+  const bool unpremultiply = alpha_ec >= 0 && m.ec[alpha_ec].alpha_associated;
+  const Channel* alpha_ch = nullptr;
+  if (unpremultiply) {
+    size_t ci = (f.encoding == 1 ? ncolor : 0) + alpha_ec;
+    JXO_CHECK(ci < d.full.ch.size(), "alpha channel missing");
+    alpha_ch = &d.full.ch[ci];
+    JXO_CHECK(alpha_ch->w == w && alpha_ch->h == h, "alpha channel size");
+  }
+  auto unpremul = [&](int y, int x) -> float {
+    const ExtraChannelInfo& ae = m.ec[alpha_ec];
+    const int32_t av = alpha_ch->Row(y)[x];
+    const float a = ae.exp_bits ? BitsToFloat(av, ae.bits, ae.exp_bits) : (float)av * (1.0f / (float)((1u << ae.bits) - 1));
+    return 1.0f / std::max(1.0f / (float)(1u << 26), a);
+  };
   if (f.encoding == 0) {
     Plane img[3];
     for (int c = 0; c < 3; c++) {
@@ -686,11 +703,13 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
           for (int c = 0; c < 3; c++) {
             float v = img[c].Row(y)[x];
             v = EncodeTransfer(tfk, v, m.intensity_target, PowerLawGamma(m.color));
+            if (unpremultiply) v *= unpremul(y, x);
             put(y, x, c, FloatToOut(v, out.bits_out, out.out_float));
           }
         } else {
           float v = img[1].Row(y)[x];
           v = EncodeTransfer(tfk, v, m.intensity_target, PowerLawGamma(m.color));
+          if (unpremultiply) v *= unpremul(y, x);
           put(y, x, 0, FloatToOut(v, out.bits_out, out.out_float));
         }
       }
@@ -701,7 +720,14 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
       JXO_CHECK(ch.w == w && ch.h == h, "modular colour channel size");
       for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-          uint32_t v = SampleToOut(ch.Row(y)[x], m.bits, m.exp_bits, out.bits_out, out.out_float);
+          uint32_t v;
+          if (unpremultiply) {
+            const int32_t sv = ch.Row(y)[x];
+            const float fv = m.exp_bits ? BitsToFloat(sv, m.bits, m.exp_bits) : (float)sv * (1.0f / (float)((1u << m.bits) - 1));
+            v = FloatToOut(fv * unpremul(y, x), out.bits_out, out.out_float);
+          } else {
+            v = SampleToOut(ch.Row(y)[x], m.bits, m.exp_bits, out.bits_out, out.out_float);
+          }
           if (out.cmyk) v = 255 - v;   // stored 0 = full ink; the host wants 0 = no ink (Decoder/JxlDecoder.cpp:199-202)
           put(y, x, c, v);
         }
@@ -721,7 +747,6 @@ void DecodeJxl(const uint8_t* data, size_t size, const DecodeOptions& opt, Decod
     const ExtraChannelInfo& ae = m.ec[alpha_ec];
     JXO_CHECK(ae.exp_bits ? ((ae.bits == 32 && ae.exp_bits == 8) || (ae.bits == 16 && ae.exp_bits == 5)) : (ae.bits >= 1 && ae.bits <= 16),
               "only integer alpha of up to 16 bits and binary16 / binary32 float alpha are supported yet");
-    JXO_CHECK(!m.ec[alpha_ec].alpha_associated, "premultiplied alpha is not supported yet");
     if (dump) dump->alpha = ch.d;
     for (int y = 0; y < h; y++)
       for (int x = 0; x < w; x++) put(y, x, nch - 1, SampleToOut(ch.Row(y)[x], ae.bits, ae.exp_bits, out.bits_out, out.out_float));

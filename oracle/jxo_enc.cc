@@ -406,7 +406,9 @@ struct VarDctEncoder {
         for (int x = 0; x < bw; x++) {
           size_t cell = (size_t)(by0 + y) * w8 + bx0 + x;
           if (!(strategy[cell] & 0x80)) continue;
-          srow.push_back(strategy[cell] & 0x7F);
+          int sw = strategy[cell] & 0x7F;
+          if (p.mislabel_afv && sw == DCT8 && (x + 2 * y) % 3 == 0) sw = AFV0 + ((x ^ y) & 3);
+          srow.push_back(sw);
           qrow.push_back(raw_quant[cell] - 1);
         }
       nb_blocks[g] = (uint32_t)srow.size();
@@ -816,7 +818,7 @@ std::vector<uint8_t> EncodeJxl(const uint8_t* px, uint32_t w, uint32_t h, int nc
   if (p.cmyk) {   // "the RGB samples are to be interpreted as CMY" + a black extra channel (+ alpha)
     m.ec.push_back(ExtraChannelInfo()); m.ec.back().type = 4; m.ec.back().bits = m.bits;
     if (nch == 5) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; }
-  } else if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; }
+  } else if (nch == 2 || nch == 4) { m.ec.push_back(ExtraChannelInfo()); m.ec.back().bits = m.bits; m.ec.back().exp_bits = m.exp_bits; m.ec.back().alpha_associated = p.premultiplied_alpha; }
   m.have_animation = p.animation_frames > 1;
   std::vector<uint8_t> frame;
   const size_t bytes_per_px = (size_t)nch * (m.bits > 16 ? 4 : (m.bits > 8 ? 2 : 1));

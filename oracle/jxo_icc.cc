@@ -101,7 +101,7 @@ std::vector<uint8_t> IccToStream(const std::vector<uint8_t>& icc) {
     else {
       cmd.Var((uint64_t)ntags + 1);
       pos = kHdr + 4;
-      uint64_t prev_start = kHdr + 4 + (uint64_t)ntags * 12, prev_size = 0;
+      uint64_t prev_start = kHdr + (uint64_t)ntags * 12, prev_size = 0;   // [spec, recalled]: without the 4 bytes of the tag count
       for (uint32_t t = 0; t < ntags; t++, pos += 12) {
         const char* name = (const char*)&icc[pos];
         const uint32_t start = BE32At(icc, pos + 4), size = BE32At(icc, pos + 8);
@@ -177,7 +177,7 @@ std::vector<uint8_t> IccFromStream(const std::vector<uint8_t>& enc) {
     ntags--;
     JXO_CHECK(ntags < (1u << 20), "ICC stream: tag count");
     be32(ntags);
-    uint64_t prev_start = kHdr + 4 + ntags * 12, prev_size = 0;
+    uint64_t prev_start = kHdr + ntags * 12, prev_size = 0;
     while (c < cend) {
       const uint32_t cm = enc[c++], code = cm & 63;
       if (!code) break;
@@ -190,8 +190,9 @@ std::vector<uint8_t> IccFromStream(const std::vector<uint8_t>& enc) {
       uint64_t start = prev_start + prev_size, size = prev_size;
       for (const char* x : {"rXYZ", "gXYZ", "bXYZ", "kXYZ", "wtpt", "bkpt", "lumi"}) if (!memcmp(name, x, 4)) size = 20;
       if (cm & 64) start = Var(enc, c, cend);
-      be32(start);
       if (cm & 128) size = Var(enc, c, cend);
+      JXO_CHECK(start <= 0xFFFFFFFFull && size <= 0xFFFFFFFFull && start + 2 * size <= 0xFFFFFFFFull, "ICC stream: tag offset or size exceeds 32 bits");
+      be32(start);
       be32(size);
       prev_start = start; prev_size = size;
       if (code == 2) { str4("gTRC"); be32(start); be32(size); str4("bTRC"); be32(start); be32(size); }
@@ -216,7 +217,7 @@ std::vector<uint8_t> IccFromStream(const std::vector<uint8_t>& enc) {
       JXO_CHECK(width != 3 && order != 3, "ICC stream: predictor parameters");
       uint64_t stride = width;
       if (fl & 16) stride = Var(enc, c, cend);
-      JXO_CHECK(stride >= width && stride * 4 < out.size(), "ICC stream: predictor stride");
+      JXO_CHECK(stride >= width && stride < (out.size() + 3) / 4, "ICC stream: predictor stride");   // no multiplication: 63-bit varint
       const size_t k = (size_t)Var(enc, c, cend), at = out.size();
       data(k);
       std::vector<uint8_t> res(out.begin() + at, out.end());

@@ -71,6 +71,19 @@ EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_parse_icc", "jx
 _lib = None
 
 
+_selftest_lib = None
+
+
+def selftest_lib():
+    """The TEST library (the product's objects + csrc/selftest.cc): writer self tests for the CPU suite.  The production library
+    does not export these hooks."""
+    global _selftest_lib
+    if _selftest_lib is None:
+        lib()   # builds if needed, checks the manifest, loads torch's HIP runtime first
+        _selftest_lib = C.CDLL(_build.test_lib_path())
+    return _selftest_lib
+
+
 class NativeLibraryMissing(RuntimeError):
     pass
 
@@ -94,10 +107,10 @@ def lib(build_if_missing=True):
     # a library built from other sources than the ones in the tree is refused, not used (and not rebuilt here: this process may already
     # hold the GPU, e.g. under a profiler)
     try:
-        built_from = open(_build.manifest_path()).read().strip()
+        built_from = open(_build.manifest_path()).read()
     except OSError:
         built_from = None
-    if built_from != _build.source_digest():
+    if built_from != _build.manifest_text():
         raise NativeLibraryMissing("%s is stale (built from different sources): run python -m pdn_jpegxl_amd.build" % path)
     try:
         L = C.CDLL(path)
@@ -330,7 +343,7 @@ class Decoder:
     def set_option(self, name, value):
         return self._L.jxlhip_set_option(self._h, name.encode(), int(value))
 
-    def decode_batch(self, files, dev_out_ptrs, dev_data_ptrs=None, stream=None, synchronize=True):
+    def decode_batch(self, files, dev_out_ptrs, dev_data_ptrs=None, stream=None, synchronize=True, raise_on_error=True):
         """files: list of bytes; dev_out_ptrs: device pointers (ints); dev_data_ptrs: device pointers of resident file bytes."""
         n = len(files)
         hd = (C.c_char_p * n)(*files)
@@ -341,8 +354,9 @@ class Decoder:
         err = ErrorInfo()
         self._keep = (hd, sz, dd, do)
         r = self._L.jxlhip_decode_batch(self._h, n, hd, sz, dd, do, stream, 1 if synchronize else 0, st, C.byref(err))
-        if r != 0:
-            raise FormatError(DECODER_STATUS[r] if 0 <= r < len(DECODER_STATUS) else str(r), err.errorMessage.decode("ascii", "replace"))
+        self.last_error = err.errorMessage.decode("ascii", "replace")
+        if r != 0 and raise_on_error:
+            raise FormatError(DECODER_STATUS[r] if 0 <= r < len(DECODER_STATUS) else str(r), self.last_error)
         return list(st)
 
     def finish(self):

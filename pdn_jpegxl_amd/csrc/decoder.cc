@@ -67,6 +67,23 @@ struct StageTimer {
 using namespace jxlhip;
 
 // Bytes per output sample: the sample type follows the colour channels' depth (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32.
+// Experiment knobs (environment variables read by tools/sweep_*.sh) exist only in a library built with -DJXLHIP_EXPERIMENTS
+// (JXLHIP_EXTRA_CFLAGS): a host process's environment must not be able to change what the shipping library decodes.
+static inline const char* Knob(const char* name) {
+#ifdef JXLHIP_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+static inline bool PowerOfTwoUpTo64(int v) { return v >= 1 && v <= 64 && (v & (v - 1)) == 0; }
+static inline int KnobStride(const char* name, int fallback) {   // lane strides: powers of two in 1..64, anything else is ignored
+  const char* e = Knob(name);
+  if (!e) return fallback;
+  const int v = atoi(e);
+  return PowerOfTwoUpTo64(v) ? v : fallback;
+}
 static inline size_t OutBytesPerSample(const ParsedFrame& f) { return f.exp_bits ? (f.bits <= 16 ? 2 : 4) : (f.bits > 8 ? 2 : 1); }
 
 // Order bucket of a quant table (every strategy of a quant table shares one bucket).
@@ -154,6 +171,7 @@ struct JxlHipDecoder {
   bool debug_taps = false;
   // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
   int band_first_row = 0, band_rows = 0;
+  bool no_direct = false, mod_lanes64 = false;   // launch shapes of the vector loops for small launches too (parity tests: same output either way)
   bool overlap = true;
 
   explicit JxlHipDecoder(int dev);
@@ -184,7 +202,7 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
   }
-  if (const char* e = getenv("JXLHIP_NO_OVERLAP")) overlap = atoi(e) == 0;
+  if (const char* e = Knob("JXLHIP_NO_OVERLAP")) overlap = atoi(e) == 0;
   const StaticTables& st = GetStaticTables();
   std::vector<float> all;
   for (int i = 0; i < 6; i++) all.insert(all.end(), st.basis[i].begin(), st.basis[i].end());
@@ -211,8 +229,8 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
     HIP_OK(hipMalloc(&d_scan[q], sl.size() * sizeof(U32x2)));
     HIP_OK(hipMemcpy(d_scan[q], sl.data(), sl.size() * sizeof(U32x2), hipMemcpyHostToDevice));
   }
-  if (const char* e = getenv("JXLHIP_LANE_STRIDE")) lane_stride_override = atoi(e);
-  if (const char* e = getenv("JXLHIP_HF_STRIDE")) hf_stride_override = atoi(e);
+  lane_stride_override = KnobStride("JXLHIP_LANE_STRIDE", 0);
+  hf_stride_override = KnobStride("JXLHIP_HF_STRIDE", 0);
 }
 
 JxlHipDecoder::~JxlHipDecoder() {
@@ -419,12 +437,12 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (!mod_rb) { mod_wp_lds = 0; mod_lanes = 64; }
   // few sections (one frame, a small batch): one section per wavefront - no divergence between sections, and row-static channels
   // decode on the scalar unit from per-residue tables (see the LF launch below)
-  if (total_mod_sections <= 512 && !getenv("JXLHIP_MOD_LANES64")) mod_lanes = 1;
+  if (total_mod_sections <= 512 && !mod_lanes64 && !Knob("JXLHIP_MOD_LANES64")) mod_lanes = 1;
   // Small launches get the Modular code's per-residue tables (the alias tables spelled out for each of the 4096 state residues,
   // 16 KB per cluster, codes of up to 8 clusters): one-section wavefronts read them through the scalar cache (RowScalar).  Measured
   // against a copy in LDS (one 4K frame): lf_ans 20.2 -> 18.8 ms, alpha_ans 5.7 -> 5.1 ms, and no LDS spent on them.
   bool global_direct = false;
-  if (!getenv("JXLHIP_NO_DIRECT")) {
+  if (!no_direct && !Knob("JXLHIP_NO_DIRECT")) {
     int pre_lf = 0;
     for (int i = 0; i < n; i++) if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) pre_lf += (int)frames[i].nlf;
     global_direct = n <= 64 && pre_lf <= 1024 && total_mod_sections <= 512;
@@ -548,6 +566,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // A band is a set of VarDCT group rows.  A Modular frame has no band mode (global Squeeze / whole-image transforms: SURVEY 8e
   // "replicas only"); its output kernel writes the whole frame, so accepting the option would overrun the caller's band buffer.
   for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok && band_rows > 0 && (band_first_row < 0 || band_first_row >= (int)frames[i].yg)) {
+      parse_status[i] = DecoderStatus_DecodeError;
+      parse_msg[i] = "band decode: the first group row lies outside the frame";
+    }
+  for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && band_rows > 0 && frames[i].encoding == 1) {
       parse_status[i] = DecoderStatus_DecodeError;
       parse_msg[i] = "band decode of a Modular (lossless) frame is not supported";
@@ -588,7 +611,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const int per_wave = 64 / lane_stride;
     const int need = (max_ng + per_wave - 1) / per_wave;
     if (need > 4 && lane_stride <= 8) hf_waves = std::min(8, need);
-    if (lane_stride == 64 && !getenv("JXLHIP_HF_WAVES8")) {
+    if (lane_stride == 64 && !Knob("JXLHIP_HF_WAVES8")) {
       // One section per wavefront: its token loop runs on the scalar unit, and a CU has ONE scalar unit - eight such wavefronts in
       // a workgroup share it (measured: hf_decode of one 4K frame 12.5 ms with 17 workgroups of 8 wavefronts).  Spread the sections
       // over as many workgroups as can be resident at once, one wavefront each if they all fit.
@@ -608,7 +631,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     return b;
   };
   size_t kHfLdsTarget = 80 * 1024;
-  if (const char* e = getenv("JXLHIP_HF_LDS_KB")) kHfLdsTarget = (size_t)atoi(e) * 1024;   // experiment knob
+  if (const char* e = Knob("JXLHIP_HF_LDS_KB")) { const int kb = atoi(e); if (kb >= 32 && kb <= 160) kHfLdsTarget = (size_t)kb * 1024; }   // experiment knob
   auto hf_per_wg = [&](const ParsedFrame& f) {
     // the fewest workgroups whose (tables + lanes) fit the budget, the image's sections spread evenly over them: every workgroup
     // carries a copy of the tables, so a small last workgroup (64 + 64 + 7 sections) costs a full LDS slot for a few lanes
@@ -643,10 +666,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // Two good shapes and a bad middle (measured, 4K frames): one section per wavefront on the scalar unit (5 ms for 135 sections,
     // degrading gently while a CU holds a dozen such wavefronts) and 32 sections per wavefront on the vector unit (12 ms for 8640
     // sections); 2 ... 16 sections per wavefront pay the vector chain for a few lanes (21 ms for 2160 sections at 2 per wavefront).
-    if (global_direct && !getenv("JXLHIP_ALPHA_OLD_SHAPES")) alpha_stride = alpha_sections > 3072 ? 2 : 64;
+    if (global_direct && !Knob("JXLHIP_ALPHA_OLD_SHAPES")) alpha_stride = alpha_sections > 3072 ? 2 : 64;
     else while (alpha_stride > 1 && alpha_sections / (64 / alpha_stride) > 256 * 8) alpha_stride >>= 1;
     if (alpha_sections >= 8192) alpha_stride = 2;   // measured: alpha_ans 27.8 ms (stride 1) / 22.5 (2) / 26.4 (4) at batch 384
-    if (const char* e = getenv("JXLHIP_ALPHA_STRIDE")) alpha_stride = atoi(e);   // experiment knob
+    alpha_stride = KnobStride("JXLHIP_ALPHA_STRIDE", alpha_stride);   // experiment knob
   }
   const int per_alpha_wg = 64 / alpha_stride;
   int n_alpha_wg = 0;
@@ -660,7 +683,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // four for large batches (fewer wavefronts and table copies for the same latency-bound time), more only for huge ones
   int lf_per_wave = total_lf <= 256 ? 1 : 4;
   while (lf_per_wave < 64 && total_lf / lf_per_wave > 4096) lf_per_wave *= 2;
-  if (const char* e = getenv("JXLHIP_LF_PER_WAVE")) lf_per_wave = std::max(1, atoi(e));   // experiment knob
+  if (const char* e = Knob("JXLHIP_LF_PER_WAVE")) lf_per_wave = std::min(64, std::max(1, atoi(e)));   // experiment knob
   int n_lf_ans = 0;
   for (int i = 0; i < n; i++)
     if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0) n_lf_ans += ((int)frames[i].nlf + lf_per_wave - 1) / lf_per_wave;
@@ -712,6 +735,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.sample_bits = (int32_t)f.bits; d.sample_exp = (int32_t)f.exp_bits;
     d.alpha_bits = d.has_alpha ? (int32_t)f.ec[f.alpha_index].bits : 8; d.alpha_exp = d.has_alpha ? (int32_t)f.ec[f.alpha_index].exp_bits : 0;
     d.out_bits = 8 * (int32_t)OutBytesPerSample(f); d.out_float = f.exp_bits ? 1 : 0;
+    d.unpremultiply = (d.has_alpha && f.ec[f.alpha_index].alpha_associated) ? 1 : 0;
+    d.alpha_unit = d.alpha_exp ? 1.0f : 1.0f / (float)((1u << d.alpha_bits) - 1);
     // band: group rows [b0, b1) are output; one more row each side is decoded for the loop-filter halo
     int b0 = 0, b1 = (int)f.yg;
     if (band_rows > 0 && f.encoding == 0) { b0 = std::min<int>(band_first_row, (int)f.yg); b1 = std::min<int>(b0 + band_rows, (int)f.yg); }
@@ -1030,7 +1055,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
         alpha_tasks[nalpha_t++] = SectionTask{i, (int32_t)g, (int32_t)std::min<uint32_t>(per_alpha_wg, ag1 - g), 0};
   }
-  if (getenv("JXLHIP_DEBUG_LDS")) {
+  if (Knob("JXLHIP_DEBUG_LDS")) {
     for (int i = 0; i < std::min(n, 8); i++)
       if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0)
         fprintf(stderr, "[jxlhip] image %d: hf tables %zu B (clusters %u, log_alpha %u, contexts %zu), lanes/wg %d; modular tables: clusters %u log_alpha %u contexts %zu tree %zu\n", i,
@@ -1049,7 +1074,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   Mark("start", s_lf, 0);
   // experiment knob (timing only, the output is stale): bit 0 skips the LF chain, 1 the HF decode, 2 alpha, 3 reconstruction, 4 filters -
   // with the same files resubmitted, a skipped stage's results of the previous batch in this workspace slot are still in place
-  static const int skip_stages = getenv("JXLHIP_SKIP_STAGES") ? atoi(getenv("JXLHIP_SKIP_STAGES")) : 0;
+  static const int skip_stages = Knob("JXLHIP_SKIP_STAGES") ? atoi(Knob("JXLHIP_SKIP_STAGES")) : 0;
   if (!(skip_stages & 1)) HIP_OK(hipMemsetAsync(d_ws, 0, zero_bytes, s_lf));
   HIP_OK(hipMemcpyAsync(d_blob, h_blob, blob.off, hipMemcpyHostToDevice, s_lf));
   Mark("upload+clear", s_lf, 0);
@@ -1289,7 +1314,8 @@ DecoderStatus JxlHipDecoder::Finish(DecoderStatus* statuses, ErrorInfo* err) {
       st = DecoderStatus_DecodeError;
       if (worst == DecoderStatus_Ok) {
         const uint32_t* w = S.h_status + (size_t)i * 16;   // [3..7]: last failing section + 1 of lf_ans / lf_finish / hf_decode / alpha_ans / modular
-        SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s; image %d, sections lf %u hf %u alpha %u)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
+        if (bits & kErrUnsupportedTransform) SetErr(err, "AFV transforms are not supported (image %d, LF group section %u)", i, w[4]);
+        else SetErr(err, "GPU decode failed (flags 0x%x:%s%s%s%s%s; image %d, sections lf %u hf %u alpha %u)", bits, bits & kErrBitstream ? " corrupt-bitstream" : "",
                bits & kErrUnsupportedHeader ? " unsupported-modular-header" : "", bits & kErrUnsupportedTree ? " unsupported-tree" : "",
                bits & kErrBlockLayout ? " invalid-varblock-layout" : "", bits & kErrRange ? " value-out-of-range" : "", i, w[3], w[5], w[6]);
       }
@@ -1379,9 +1405,13 @@ int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
   if (!dec || !name) return 0;
   if (!strcmp(name, "debug_taps")) { dec->debug_taps = value != 0; return 1; }
   if (!strcmp(name, "query_pixel_chunk")) return JxlHipDecoder::kPixelChunk;
-  if (!strcmp(name, "lane_stride")) { dec->lane_stride_override = value; return 1; }
-  if (!strcmp(name, "band_first_row")) { dec->band_first_row = value; return 1; }
-  if (!strcmp(name, "band_rows")) { dec->band_rows = value; return 1; }
+  // values a kernel's indexing depends on are validated here: a negative band start would put pixel rows in front of the caller's
+  // band buffer, a stride that is not a power of two breaks the section -> lane mapping
+  if (!strcmp(name, "lane_stride")) { if (value != 0 && !PowerOfTwoUpTo64(value)) return 0; dec->lane_stride_override = value; return 1; }
+  if (!strcmp(name, "band_first_row")) { if (value < 0) return 0; dec->band_first_row = value; return 1; }
+  if (!strcmp(name, "band_rows")) { if (value < 0) return 0; dec->band_rows = value; return 1; }
+  if (!strcmp(name, "no_direct")) { dec->no_direct = value != 0; return 1; }
+  if (!strcmp(name, "mod_lanes64")) { dec->mod_lanes64 = value != 0; return 1; }
   if (!strcmp(name, "overlap")) { dec->overlap = value != 0; return 1; }
   return 0;
 }

@@ -26,6 +26,7 @@ enum DevError : uint32_t {
   kErrUnsupportedTree = 1u << 2,    // weighted predictor / reference-channel properties on the GPU path
   kErrBlockLayout = 1u << 3,        // invalid varblock placement
   kErrRange = 1u << 4,              // value out of range (sharpness, quant, cfl)
+  kErrUnsupportedTransform = 1u << 5,   // AFV0..AFV3 varblocks (strategy ids 14..17): their 16x16 basis is not built; never decoded as anything else
 };
 
 struct alignas(8) U32x2 { uint32_t x, y; };   // 8 bytes, 8-byte aligned loads / stores on the device
@@ -85,6 +86,9 @@ struct DevImage {
   // output sample type chosen from the colour depth like the reference does (Decoder/JxlDecoder.cpp:510-556): u8, u16, f16, f32
   int32_t sample_bits, alpha_bits, out_bits, out_float;   // out_float: out_bits 16 / 32 are binary16 / binary32 samples
   int32_t sample_exp, alpha_exp;                          // exponent bits of float-coded channels (0: integer samples)
+  // alpha is associated (premultiplied): the encoded colour samples are multiplied by 1 / max(alpha, 2^-26) where they are written,
+  // as the reference asks of its library (Decoder/JxlDecoder.cpp:233); alpha_unit = 1 / (2^alpha_bits - 1)
+  int32_t unpremultiply; float alpha_unit;
   // codestream
   const uint8_t* cs;
   uint64_t cs_size;

@@ -1172,6 +1172,9 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
       const int es = s_info[i], eq = 1 + s_info[count + i];
       const bool ok = es >= 0 && es < kNumStrategies && eq >= 1 && eq <= 256;
       if (!ok) err |= kErrBlockLayout;
+      // AFV0..AFV3: the strategy ids are only known here (the block-metadata stream is decoded on the GPU), so this is where the
+      // frame is refused; the group keeps no varblock (s_count = 0 below), nothing downstream reconstructs it
+      if (es >= 14 && es <= 17) err |= kErrUnsupportedTransform | kErrBlockLayout;
       sum += ok ? 1u << d_log2cx[es] : 1u;
     }
     s_part[tid] = sum;
@@ -1269,7 +1272,7 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
         im.rawq[cc] = (uint16_t)q;
       }
   }
-  if (err) SetError(im, err);
+  if (err) SetError(im, err, 2, g);
 }
 
 // ------------------------------------------------------------------ HF coefficients
@@ -1975,12 +1978,23 @@ __global__ void modular_out_kernel(const DevImage* imgs) {
     }
     // colour channels carry sample_bits / sample_exp, the alpha channel alpha_bits / alpha_exp, the black channel black_bits
     const int ncol = im.ncolor;
+    float unmul = 1.0f;   // associated alpha: colour samples leave as float(sample) / max(float(alpha), 2^-26)
+    if (im.unpremultiply) {
+      int32_t av = 0;
+      for (int c = ncol; c < nch; c++) if (im.mod_out_pos[c] == nch - 1) av = v[c];
+      const float af = im.alpha_exp ? BitsToFloatSample(av, im.alpha_bits) : (float)av * im.alpha_unit;
+      unmul = 1.0f / fmaxf(1.0f / 67108864.0f, af);
+    }
     for (int c = 0; c < nch; c++) {
       const int pos = im.mod_out_pos[c];
       const bool is_alpha = im.has_alpha && pos == nch - 1;
       const bool is_black = im.cmyk && pos == 3;
       uint32_t s = SampleToOutBits(v[c], c < ncol ? im.sample_bits : (is_alpha ? im.alpha_bits : im.black_bits), c < ncol ? im.sample_exp : (is_alpha ? im.alpha_exp : 0),
                                    im.out_bits, im.out_float);
+      if (im.unpremultiply && c < ncol) {
+        const float f = im.sample_exp ? BitsToFloatSample(v[c], im.sample_bits) : (float)v[c] * (1.0f / (float)((1u << im.sample_bits) - 1));
+        s = FloatToOutBits(f * unmul, im.out_bits, im.out_float);
+      }
       if (im.cmyk && !is_alpha) { (void)is_black; s = 255u - s; }   // 8-bit CMYK only (checked on the host)
       StoreOutSample(im.out, i * nch + pos, s, im.out_bits);
     }

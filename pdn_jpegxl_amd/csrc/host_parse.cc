@@ -1506,7 +1506,11 @@ void ParseFile(const uint8_t* data, size_t size, bool headers_only, ParsedFrame&
   if (f.alpha_index >= 0 && !depth_ok(f.ec[f.alpha_index].bits, f.ec[f.alpha_index].exp_bits))
     Fail("only integer alpha of up to 16 bits and binary16 / binary32 float alpha are supported yet");
   // the reference asks for un-premultiplied output (Decoder/JxlDecoder.cpp:233): premultiplied streams would need the division
-  if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated) Fail("premultiplied alpha is not supported yet");
+  // - done where the samples are written.  VarDCT frames keep their alpha plane in the OUTPUT sample type, so the division there is
+  // exact only when that type is the alpha channel's own integer depth; Modular frames divide by the coded sample (any depth).
+  if (f.alpha_index >= 0 && f.ec[f.alpha_index].alpha_associated && f.encoding == 0 &&
+      (f.exp_bits || f.ec[f.alpha_index].exp_bits || f.ec[f.alpha_index].bits != (f.bits > 8 ? 16u : 8u)))
+    Fail("premultiplied alpha whose depth differs from the output samples' is not supported yet on lossy frames");
   for (auto& e : f.ec) if (e.dim_shift) Fail("subsampled extra channels are not supported yet");
   if (PlanColor(f).known_profile < 0 && !PlanColor(f).report_icc)
     Fail("colour encodings other than D65 sRGB / linear sRGB / Display P3 / BT.709 / BT.2020 linear / BT.2020 PQ / gray need an ICC profile, which is not built yet");

@@ -184,7 +184,8 @@ bool IccUnpredict(const std::vector<uint8_t>& enc, std::vector<uint8_t>* icc, st
     ntags--;
     if (ntags > (1u << 20)) return fail("ICC stream: tag count");
     PutU32((uint32_t)ntags, &out);
-    uint64_t prev_start = kHeaderSize + 4 + ntags * 12, prev_size = 0;
+    // the predictor's first "previous tag" ends where a tag table WITHOUT its 4-byte count would end  [spec, recalled; unpinned]
+    uint64_t prev_start = kHeaderSize + ntags * 12, prev_size = 0;
     for (;;) {
       if (out.size() > osize) return fail("ICC stream: tag table exceeds the profile");
       if (cpos == cend) break;
@@ -205,8 +206,10 @@ bool IccUnpredict(const std::vector<uint8_t>& enc, std::vector<uint8_t>* icc, st
       static const char* const kXyzLike[7] = {"rXYZ", "gXYZ", "bXYZ", "kXYZ", "wtpt", "bkpt", "lumi"};
       for (auto t : kXyzLike) if (!memcmp(tag, t, 4)) size = 20;
       if (command & 64) { if (!GetVarint(enc, &cpos, cend, &start)) return fail("ICC stream: truncated tag offset"); }
-      PutU32((uint32_t)start, &out);
       if (command & 128) { if (!GetVarint(enc, &cpos, cend, &size)) return fail("ICC stream: truncated tag size"); }
+      // offsets and sizes are 32-bit fields of the profile: anything wider is a broken stream, not something to truncate
+      if (start > 0xFFFFFFFFull || size > 0xFFFFFFFFull || start + 2 * size > 0xFFFFFFFFull) return fail("ICC stream: tag offset or size exceeds 32 bits");
+      PutU32((uint32_t)start, &out);
       PutU32((uint32_t)size, &out);
       prev_start = start; prev_size = size;
       if (code == 2) {   // the three tone curves usually share one curve
@@ -242,7 +245,8 @@ bool IccUnpredict(const std::vector<uint8_t>& enc, std::vector<uint8_t>* icc, st
       if (width == 3 || order == 3) return fail("ICC stream: predictor parameters");
       uint64_t stride = width, n;
       if (flags & 16) { if (!GetVarint(enc, &cpos, cend, &stride) || stride < width) return fail("ICC stream: predictor stride"); }
-      if (stride * 4 >= out.size()) return fail("ICC stream: predictor stride exceeds the data");
+      // (compared without multiplying: the stride is a varint of up to 63 bits)
+      if (stride >= (out.size() + 3) / 4) return fail("ICC stream: predictor stride exceeds the data");
       std::vector<uint8_t> run;
       if (!GetVarint(enc, &cpos, cend, &n) || !take((size_t)n, &run)) return fail("ICC stream: predictor run");
       if (width > 1) Unshuffle(&run, width);

@@ -449,7 +449,7 @@ __global__ void idct_special_kernel(const DevImage* imgs, const float* basis_all
         }
       }
     } else {
-      for (int k = 0; k < 64; k++) px[k] = 0.f;   // AFV: rejected on the host
+      for (int k = 0; k < 64; k++) px[k] = 0.f;   // unreachable: lf_finish_kernel refuses AFV ids (kErrUnsupportedTransform) and places no block of such a group
     }
     for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) dst[(size_t)y * im.wp + x] = px[y * 8 + x];
   }

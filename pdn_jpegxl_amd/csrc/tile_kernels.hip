@@ -101,6 +101,10 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
     r = EncodeTransferT(im.to_srgb, r, im.pq_scale, im.trc_lut); g = EncodeTransferT(im.to_srgb, g, im.pq_scale, im.trc_lut + 4096);
     bl = EncodeTransferT(im.to_srgb, bl, im.pq_scale, im.trc_lut + 8192);
   }
+  if (im.unpremultiply) {   // associated alpha: the encoded samples are divided by max(alpha, 2^-26) (Decoder/JxlDecoder.cpp:233)
+    const float m = 1.0f / fmaxf(1.0f / 67108864.0f, (float)a * im.alpha_unit);
+    r *= m; g *= m; bl *= m;
+  }
   const size_t o = (size_t)(y - im.band_y0) * im.w + x;        // position in the output band
   if (im.out_bits != 8) {   // u16 above 8 bits per sample, f16 / f32 for float samples (Decoder/JxlDecoder.cpp:510-548); `a` is raw bits
     const size_t b = o * im.nch_out;
@@ -131,7 +135,7 @@ __device__ __forceinline__ void WritePixelA(const DevImage& im, int x, int y, fl
 }
 // The common layouts (u8 samples, sRGB or linear transfer) without the branches of the general function: used by the fused filter
 // kernel, whose output phase is a large part of its time.
-__device__ __forceinline__ bool PlainOutput(const DevImage& im) { return im.out_bits == 8 && im.to_srgb <= 1; }
+__device__ __forceinline__ bool PlainOutput(const DevImage& im) { return im.out_bits == 8 && im.to_srgb <= 1 && !im.unpremultiply; }
 // Out of line on purpose: inlined four times into the fused filter kernel's unrolled output phase, the general function more than
 // doubled that kernel's code (2.3 k -> 5.8 k instructions) and cost 8 % of its speed on the plain path that never executes it.
 __device__ __noinline__ void WritePixelGeneral(const DevImage& im, int x, int y, float X, float Y, float B, uint32_t a) {

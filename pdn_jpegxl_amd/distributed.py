@@ -53,6 +53,7 @@ def decode_frame_band(dec, data, rank, world, device="cuda"):
             st = dec.decode_batch([data], [out.data_ptr()], None, synchronize=True)
         finally:
             dec.set_option("band_rows", 0)
+            dec.set_option("band_first_row", 0)
         if st[0] != 0:
             raise RuntimeError("band decode failed with status %d" % st[0])
     return out[: (y1 - y0) * row_bytes], (y0, y1)
@@ -108,6 +109,7 @@ class BandDecoder:
             st = self.dec.decode_batch([self.data], [self.band.data_ptr()], [self.src.data_ptr()], synchronize=True)
         finally:
             self.dec.set_option("band_rows", 0)
+            self.dec.set_option("band_first_row", 0)
         if st[0] != 0:
             raise RuntimeError("band decode failed with status %d" % st[0])
 

@@ -82,7 +82,8 @@ class OracleError(RuntimeError):
 
 def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, seed=1, epf_iters=-1, gaborish=True,
            container=True, adaptive_lf_smoothing=True, lossless_predictor=6, lossless_squeeze=False, num_threads=8, exif=None,
-           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0, icc=None, cmyk=False, animation_frames=1, custom_quant_tables=False, prefix_codes=False, lz77=False, num_passes=1, custom_orders=False, lf_contexts=False, palette=False):
+           xmp=None, lossless_tree=0, bits=8, orientation=1, float_samples=0, colour=0, icc=None, cmyk=False, animation_frames=1, custom_quant_tables=False, prefix_codes=False, lz77=False, num_passes=1, custom_orders=False, lf_contexts=False, palette=False, mislabel_afv=False,
+           premultiplied_alpha=False):
     """px: uint8 array (h, w, nch) with nch in 1..4 (Gray, GrayA, RGB, RGBA); with bits > 8 (up to 16) a uint16 array whose
     samples use the low `bits` bits; with float_samples = 16 / 32 a float16 / float32 array (nominal range [0, 1]).  Returns bytes."""
     L = lib()
@@ -95,9 +96,10 @@ def encode(px, distance=1.0, lossless=False, strategy_mode=0, fixed_strategy=0, 
     h, w, nch = px.shape
     p = EncodeParams(distance, int(lossless), 7, strategy_mode, fixed_strategy, seed, epf_iters, int(gaborish), int(container),
                      int(adaptive_lf_smoothing), lossless_predictor, int(lossless_squeeze), lossless_tree, num_threads, bits, orientation, float_samples, colour)
-    if custom_quant_tables or prefix_codes or lz77 or num_passes > 1 or custom_orders or lf_contexts or palette:
+    if custom_quant_tables or prefix_codes or lz77 or num_passes > 1 or custom_orders or lf_contexts or palette or mislabel_afv or premultiplied_alpha:
         L.jxo_set_next_flags.argtypes = [C.c_uint32]
-        L.jxo_set_next_flags((1 if custom_quant_tables else 0) | (2 if prefix_codes else 0) | (4 if lz77 else 0) | {1: 0, 2: 8, 3: 16}[num_passes] | (32 if custom_orders else 0) | (64 if lf_contexts else 0) | (128 if palette else 0))
+        L.jxo_set_next_flags((1 if custom_quant_tables else 0) | (2 if prefix_codes else 0) | (4 if lz77 else 0) | {1: 0, 2: 8, 3: 16}[num_passes] | (32 if custom_orders else 0) | (64 if lf_contexts else 0) | (128 if palette else 0) |
+                             (256 if mislabel_afv else 0) | (512 if premultiplied_alpha else 0))
     if animation_frames > 1:
         L.jxo_set_next_animation.argtypes = [C.c_int]
         L.jxo_set_next_animation(animation_frames)

@@ -209,3 +209,44 @@ def test_unnamed_colour_encodings_are_refused(oracle):
         with pytest.raises(api.JxlError) as e:
             api.load_image(data)
         assert e.value.status == "DecodeError"
+
+
+def _premultiplied(img, maxv):
+    """Straight RGBA (integers) -> colour samples multiplied by alpha / maxv, rounded: what a file with associated alpha stores."""
+    a = img[..., -1:].astype(np.float64) / maxv
+    out = img.copy()
+    out[..., :-1] = np.round(img[..., :-1].astype(np.float64) * a).astype(img.dtype)
+    return out
+
+
+@pytest.mark.parametrize("lossless", [True, False], ids=["lossless", "lossy"])
+@pytest.mark.parametrize("bits", [8, 16])
+def test_premultiplied_alpha_is_undone(oracle, lossless, bits):
+    """Associated alpha: the reference asks its library for un-premultiplied samples (JxlDecoderSetUnpremultiplyAlpha(TRUE),
+    Decoder/JxlDecoder.cpp:233).  The division is done where the samples are written, on the encoded values, with alpha clamped
+    from below at 2^-26 [recalled from the library; unpinned].  Checked against the oracle, and against ground truth: where alpha
+    is large the straight colour comes back to within the rounding of the premultiplied samples."""
+    img = synth(300, 200, 12) if bits == 8 else synth16(300, 200, 12)
+    maxv = (1 << bits) - 1
+    img[10:40, 10:60, 3] = 0                 # fully transparent: division by the clamp, samples saturate or stay 0
+    img[50:60, :, 3] = maxv
+    pm = _premultiplied(img, maxv)
+    data = oracle.encode(pm, lossless=lossless, bits=bits, premultiplied_alpha=True, lossless_predictor=5, lossless_tree=1)
+    got, ref = api.load_image(data), oracle.decode(data)
+    assert got.has_transparency and np.array_equal(got.pixels[..., 3], img[..., 3])
+    d = np.abs(got.pixels.astype(np.int64) - ref.pixels.astype(np.int64))
+    if lossless:
+        assert d.max() <= 1 and (d > 0).mean() < 1e-3      # one float32 multiply on both sides
+        # ground truth where alpha >= half: |straight - recovered| <= about maxv / (2 alpha) + 1 from the rounding of the stored sample
+        m = img[..., 3] >= maxv // 2
+        err = np.abs(got.pixels[..., :3].astype(np.float64) - img[..., :3].astype(np.float64))[m]
+        assert err.max() <= 2.0
+        assert (got.pixels[10:40, 10:60, :3] == 0).all()   # 0 / clamp = 0
+    else:
+        tol = 1 if bits == 8 else 48
+        # the division amplifies float differences by 1 / alpha: compare where alpha is at least a quarter
+        m = img[..., 3] >= maxv // 4
+        assert d[..., :3][m].max() <= 4 * tol and (d[..., :3][m] > tol).mean() < 0.002
+    # the same file with the flag off keeps the stored (premultiplied) samples
+    plain = api.load_image(oracle.encode(pm, lossless=True, bits=bits, lossless_predictor=5, lossless_tree=1))
+    assert np.array_equal(plain.pixels, pm)

@@ -233,19 +233,69 @@ def test_explicit_quantisation_tables(gpu_decoder, oracle):
 
 
 def test_corrupt_prefix_and_lz77_streams_fail_cleanly(gpu_decoder, oracle):
+    """Bit flips in the section data: the decode either ends in an error status, or - when the flips only touched raw bits /
+    padding, which no entropy coder can notice - it yields what the oracle yields for the same damaged stream.  Nothing else counts
+    as a pass (in particular no exception of the harness), and nothing may crash or hang."""
+    import torch
     img = synth(520, 300, 74)
     data = bytearray(oracle.encode(img, prefix_codes=True, lz77=True))
     rng = np.random.default_rng(3)
-    bad = 0
+    detected = 0
     for k in range(12):
         d = bytearray(data)
         for p in rng.integers(len(d) // 3, len(d), 6):
             d[p] ^= 1 << int(rng.integers(0, 8))
+        d = bytes(d)
+        info = api.peek(d)
+        out = torch.zeros(info.width * info.height * info.num_channels, dtype=torch.uint8, device="cuda")
+        st = gpu_decoder.decode_batch([d], [out.data_ptr()], None, raise_on_error=False)
+        if st[0] != 0:
+            assert st[0] == api.DECODER_STATUS.index("DecodeError"), st
+            detected += 1
+            continue
         try:
-            gpu_decode(gpu_decoder, [bytes(d)])
-        except (api.FormatError, AssertionError):
-            bad += 1
-    assert bad >= 6   # most corruptions are detected (final states, ranges); none may crash or hang
+            ref = oracle.decode(d).pixels
+        except oracle.OracleError as e:
+            pytest.fail("stream %d: status Ok for a stream the oracle refuses (%s)" % (k, e))
+        check_pixels(out.cpu().numpy().reshape(ref.shape), ref)
+    assert detected >= 1
+
+
+def test_afv_varblocks_are_refused_loudly(oracle):
+    """AFV0..AFV3 (strategy ids 14..17) are not built: a stream that labels blocks so must end in DecodeError with a message that
+    says so - through LoadImage, the call the reference's host makes (Decoder/JxlDecoder.cpp:252, errors :837-849) - never in
+    status Ok with unwritten blocks.  The stream comes from the oracle's writer with some 8x8 blocks labelled AFV (refusal test
+    switch; the oracle's own decoder refuses AFV as well)."""
+    for size in ((520, 300), (200, 150)):          # several groups / a one-group frame
+        data = oracle.encode(synth(size[0], size[1], 3), mislabel_afv=True)
+        with pytest.raises(oracle.OracleError):
+            oracle.decode(data)
+        with pytest.raises(api.FormatError) as e:
+            api.load_image(data)
+        assert e.value.status == "DecodeError"
+        assert "AFV" in str(e.value)
+    # the same picture without the labels decodes
+    api.load_image(oracle.encode(synth(200, 150, 3)))
+
+
+def test_band_options_are_validated(gpu_decoder, oracle):
+    """A negative first band row would put pixel rows in front of the caller's band buffer (advisor, round 2): the option is refused,
+    and a band that starts past the frame fails the frame."""
+    import torch
+    assert gpu_decoder.set_option("band_first_row", -1) == 0
+    assert gpu_decoder.set_option("band_rows", -5) == 0
+    assert gpu_decoder.set_option("lane_stride", 3) == 0 and gpu_decoder.set_option("lane_stride", 128) == 0
+    data = oracle.encode(synth(300, 520, 5))
+    info = api.peek(data)
+    out = torch.zeros(info.width * info.height * info.num_channels, dtype=torch.uint8, device="cuda")
+    try:
+        assert gpu_decoder.set_option("band_first_row", 7) and gpu_decoder.set_option("band_rows", 1)
+        st = gpu_decoder.decode_batch([data], [out.data_ptr()], None, raise_on_error=False)
+        assert st[0] == api.DECODER_STATUS.index("DecodeError")
+    finally:
+        gpu_decoder.set_option("band_rows", 0)
+        gpu_decoder.set_option("band_first_row", 0)
+    check_pixels(gpu_decode(gpu_decoder, [data])[0], oracle.decode(data).pixels)
 
 
 @pytest.mark.parametrize("passes", [2, 3])
@@ -312,7 +362,7 @@ def test_block_contexts_from_lf_and_quant_field_thresholds(gpu_decoder, oracle, 
     run_case(gpu_decoder, oracle, small, lf_contexts=True)
 
 
-def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle, monkeypatch):
+def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle):
     """One-section wavefronts decode on the scalar unit (per-residue tables through the scalar cache, counted HF token loop); many
     sections per wavefront use the vector loops.  Same streams, both shapes of launch: the outputs must be byte-identical.
     Covers a lossy RGBA frame (LF, HF, alpha rows), a product-encoded lossless frame and an oracle lossless frame with West rows."""
@@ -321,10 +371,14 @@ def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle, monkeypat
                api.save_image(np.ascontiguousarray(img[..., [2, 1, 0, 3]]), lossless=True),
                oracle.encode(np.ascontiguousarray(img[..., :3]), lossless=True, lossless_tree=0, lossless_predictor=1)]
     scalar = [gpu_decode(gpu_decoder, [s])[0] for s in streams]
-    monkeypatch.setenv("JXLHIP_NO_DIRECT", "1")      # no per-residue tables: the vector row loops on one lane
-    vector1 = [gpu_decode(gpu_decoder, [s])[0] for s in streams]
-    monkeypatch.setenv("JXLHIP_MOD_LANES64", "1")    # Modular sections 64 to a wavefront
-    vector2 = [gpu_decode(gpu_decoder, [s], lane_stride=2)[0] for s in streams]   # HF / alpha sections 32 to a wavefront
+    try:
+        assert gpu_decoder.set_option("no_direct", 1)      # no per-residue tables: the vector row loops on one lane
+        vector1 = [gpu_decode(gpu_decoder, [s])[0] for s in streams]
+        assert gpu_decoder.set_option("mod_lanes64", 1)    # Modular sections 64 to a wavefront
+        vector2 = [gpu_decode(gpu_decoder, [s], lane_stride=2)[0] for s in streams]   # HF / alpha sections 32 to a wavefront
+    finally:
+        gpu_decoder.set_option("no_direct", 0)
+        gpu_decoder.set_option("mod_lanes64", 0)
     for a, b, c in zip(scalar, vector1, vector2):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)

@@ -172,7 +172,7 @@ def test_golden_files_parse(oracle):
 # ---------------------------------------------------------------- encoder-side host writers (no GPU)
 def _selftests():
     import ctypes as C
-    L = api.lib()
+    L = api.selftest_lib()
     L.jxlhip_selftest_entropy.restype = C.c_int32
     L.jxlhip_selftest_entropy.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_uint32, C.POINTER(api.ErrorInfo)]
     L.jxlhip_selftest_tree.restype = C.c_int32
@@ -203,7 +203,7 @@ def test_encoder_tree_reads_back(nlf):
 def test_encoder_headers_read_back(w, h, gray, alpha, lossless, epf):
     """WriteCodestreamHeaders + WriteFrameHeader + WriteToc + WriteContainer (host_write.cc) -> ParseFile (host_parse.cc): geometry,
     channel layout, loop-filter settings and the section table survive the trip."""
-    L = api.lib()
+    L = api.selftest_lib()
     L.jxlhip_selftest_headers.restype = C.c_size_t
     L.jxlhip_selftest_headers.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t]
     buf = (C.c_uint8 * (1 << 22))()

@@ -76,7 +76,7 @@ def test_oracle_file_with_profile_is_parsed_by_the_product(k):
 
 
 def test_product_header_writer_roundtrip():
-    L = api.lib()
+    L = api.selftest_lib()
     L.jxlhip_selftest_headers_icc.restype = C.c_size_t
     L.jxlhip_selftest_headers_icc.argtypes = [C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t]
     for icc in PROFILES:
@@ -140,7 +140,9 @@ def test_hand_built_command_stream():
     icc = hdr + struct.pack(">I", 6) + b"".join(n + struct.pack(">II", o, s) for n, o, s in entries) + body
     assert len(icc) == size
     commands = varint(6 + 1)
-    commands += bytes([2 | 128]) + varint(12)      # rTRC (+ gTRC, bTRC): offset implied (right after the table), size given
+    # rTRC (+ gTRC, bTRC): offset AND size given - the implied first offset is 128 + 12 * ntags, four bytes before the end of a
+    # real tag table (the count is not part of the prediction; recalled from the published format, unpinned), see the test below
+    commands += bytes([2 | 64 | 128]) + varint(table_end) + varint(12)
     commands += bytes([3])                         # rXYZ (+ gXYZ, bXYZ): offset implied (after the curve), size implied (20)
     commands += bytes([0])                         # end of the table
     data = header_residuals(icc)
@@ -164,7 +166,8 @@ def test_hand_built_command_stream():
     # truncated and corrupted streams are refused, not crashed on
     assert product_unpredict(enc[:-3]) is None and oracle_unpredict(enc[:-3]) is None
     bad = bytearray(enc)
-    bad[len(varint(size)) + 1 + 3] = 63            # an unknown tag code
+    bad[len(varint(size)) + 1 + 5] = 63            # an unknown tag code (in place of the rXYZ command)
+    assert enc[len(varint(size)) + 1 + 5] == 3
     assert product_unpredict(bytes(bad)) is None and oracle_unpredict(bytes(bad)) is None
 
 
@@ -201,3 +204,54 @@ def test_profiles_that_need_a_real_cms_are_recognised():
         assert L.jxlhip_icc_model(icc, len(icc), model.ctypes.data, None, None) == 0
     g = icc_util.gray_profile()
     assert L.jxlhip_icc_model(g, len(g), model.ctypes.data, None, None) == 2
+
+
+def test_implied_first_tag_offset_and_wide_fields():
+    """The first tag's implied offset is 128 + 12 * ntags (hand-assembled, not written by either encoder); offsets or sizes that
+    do not fit the profile's 32-bit fields are refused, not truncated."""
+    def stream(first):
+        size = 128 + 4 + 12 + 8
+        hdr = (struct.pack(">I", size) + b"abcd" + b"\x04\x30\0\0" + b"mntrRGB XYZ " + b"\0" * 12 + b"acspMSFT" + b"\0" * 88)[:128]
+        commands = varint(1 + 1) + first + bytes([0]) + bytes([1]) + varint(8)
+        data = header_residuals(hdr + b"\0" * 24) + b"desc" + bytes(range(8))
+        return hdr, varint(size) + varint(len(commands)) + commands + data
+    hdr, enc = stream(bytes([1 | 128]) + varint(8))          # unknown tag name from the data stream, implied offset, size 8
+    want = hdr + struct.pack(">I", 1) + b"desc" + struct.pack(">II", 128 + 12, 8) + bytes(range(8))
+    assert product_unpredict(enc) == want and oracle_unpredict(enc) == want
+    for off, sz in ((1 << 32, 8), (140, 1 << 32), (0xFFFFFFF0, 0x10)):
+        _, bad = stream(bytes([1 | 64 | 128]) + varint(off) + varint(sz))
+        assert product_unpredict(bad) is None and oracle_unpredict(bad) is None, (off, sz)
+
+
+@pytest.mark.parametrize("stride", [1 << 62, (1 << 63) - 1, (1 << 62) + 1, 1 << 32, 33, 34])
+def test_predictor_stride_is_checked_without_overflow(stride):
+    """A 63-bit stride used to pass `stride * 4 >= size` by wrapping and index far outside the profile (advisor, round 2)."""
+    commands = varint(0) + bytes([1]) + varint(4) + bytes([4, 0x10]) + varint(stride) + varint(4)
+    data = bytes(128) + bytes([1, 2, 3, 4]) + bytes(4)
+    enc = varint(136) + varint(len(commands)) + commands + data
+    got_p, got_o = product_unpredict(enc), oracle_unpredict(enc)
+    if stride * 4 < 132:        # the only legal one of the list: 32 * 4 < 132 fails, 33 * 4 = 132 fails too -> none legal but keep the rule visible
+        assert got_p is not None and got_p == got_o
+    else:
+        assert got_p is None and got_o is None
+
+
+def test_icc_unpredict_under_asan(tmp_path):
+    """Byte-mutation fuzz of the product's ICC stream reader under CPU AddressSanitizer (tests/native/icc_fuzz_main.cc): the code is
+    reachable from LoadImage with an untrusted file, and a try/catch does not catch a wild read."""
+    import os
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    exe = str(tmp_path / "icc_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           os.path.join(here, "native", "icc_fuzz_main.cc"), os.path.join(root, "pdn_jpegxl_amd", "csrc", "icc.cc"), "-o", exe])
+    seeds = []
+    for k, icc in enumerate(PROFILES[:4]):
+        path = str(tmp_path / ("seed%d.bin" % k))
+        with open(path, "wb") as f:
+            f.write(oracle_predict(icc))
+        seeds.append(path)
+    r = subprocess.run([exe] + seeds, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode(errors="replace")[-2000:]
+    assert b"no crash" in r.stdout

@@ -248,3 +248,21 @@ def test_palette_round_trip(oracle, nch):
         data = oracle.encode(img, lossless=True, palette=True, lossless_squeeze=squeeze)
         assert (oracle.decode(data).pixels == img).all()
         assert len(data) < len(oracle.encode(img, lossless=True, lossless_squeeze=squeeze))
+
+
+def test_premultiplied_alpha_oracle_identity(oracle):
+    O = oracle
+    """Oracle alone (CPU): a lossless stream with associated alpha decodes to samples / max(alpha, 2^-26), i.e. the straight colour up
+    to the rounding of the stored premultiplied samples; without the flag the stored samples come back untouched."""
+    img = synth(120, 90, 12)
+    img[5:20, 5:30, 3] = 0
+    a = img[..., 3:].astype(np.float64) / 255
+    pm = img.copy()
+    pm[..., :3] = np.round(img[..., :3] * a).astype(np.uint8)
+    dec = O.decode(O.encode(pm, lossless=True, premultiplied_alpha=True))
+    assert np.array_equal(dec.pixels[..., 3], img[..., 3])
+    m = img[..., 3] >= 128
+    assert np.abs(dec.pixels[..., :3].astype(np.float64) - img[..., :3])[m].max() <= 2.0
+    want = np.clip(np.floor(pm[..., :3].astype(np.float32) / 255 * (1 / np.maximum(np.float32(2.0 ** -26), (img[..., 3:] / np.float32(255)).astype(np.float32))) * 255 + 0.5), 0, 255)
+    assert np.abs(dec.pixels[..., :3].astype(np.float64) - want).max() <= 1
+    assert np.array_equal(O.decode(O.encode(pm, lossless=True)).pixels, pm)

@@ -405,7 +405,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   const size_t off_imgs = blob.Take(sizeof(DevImage) * (size_t)(n + n_extra));
   struct PassLayout {   // what a pass owns: its code, scan lists, entry lists, block index, end positions, LZ77 windows
-    size_t a_cmap, a_cfg, a_alias, a_pfx[3] = {}, lz_hf = 0, scan[kNumQuantTables] = {}, centries, cblk, bitpos;
+    size_t a_cmap, a_cfg, a_alias, a_pfx[3] = {}, lz_hf = 0, scan[kNumQuantTables] = {}, centries, cblk, bitpos, hf_order;
   };
   struct PerImg {
     std::vector<PassLayout> extra;
@@ -416,7 +416,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     size_t scan[kNumQuantTables] = {};   // frames with their own coefficient orders: scan lists of the affected quant tables
     size_t trc_lut = 0;                  // tone-curve tables of an evaluated ICC profile (+1; 0: none)
     size_t dq[kNumQuantTables] = {};     // frames with their own dequantisation tables (+1; 0: the library table)
-    size_t z_cellinfo, z_status, centries, cblk;
+    size_t z_cellinfo, z_status, centries, cblk, hf_order;
     std::vector<size_t> mod_planes;
     size_t mod_chan, mod_desc, wp_lf, wp_grp, lf_end, alpha32;
     size_t lf[3], lf_tmp[3], lfq[3], lf_extra, rawq, sharp, ytox, ytob, binfo, lf_desc, lf_count, alpha_desc, blk_list, blk_count, bitpos, tile_list, tmp[3], xyb[3], inv_sigma, alpha;
@@ -455,6 +455,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     const size_t cells = (size_t)f.w8 * f.h8, pix = cells * 64, tiles = (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8);
     l.sec_off = blob.Take(8 * f.sec_off.size());
     l.sec_size = blob.Take(4 * f.sec_size.size());
+    l.hf_order = blob.Take(4 * (size_t)std::max<uint32_t>(1, f.ng));
     l.tree = blob.Take(sizeof(DevTreeNode) * f.tree.size());
     l.m_cmap = blob.Take(f.mcode.ctx_map.size());
     l.m_cfg = blob.Take(4 * f.mcode.cfg.size());
@@ -521,6 +522,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
         pl.centries = ws.Take((size_t)std::max(1, g1 - g0) * f.xg * kGroupEntriesCap * 4);
         pl.cblk = ws.Take(3 * cells * sizeof(U32x2));
         pl.bitpos = ws.Take((size_t)f.ng * 8);
+        pl.hf_order = blob.Take(4 * (size_t)std::max<uint32_t>(1, f.ng));
         l.extra.push_back(pl);
       }
     }
@@ -1042,14 +1044,27 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     }
     const uint32_t hg0 = (uint32_t)d.dec_gy0 * f.xg, hg1 = (uint32_t)d.dec_gy1 * f.xg;
     const uint32_t pw = (uint32_t)hf_per_wg(f);
-    for (uint32_t pass = 0; pass < f.num_passes; pass++)
-      for (uint32_t g = hg0; g < hg1; g += pw) {
-        const uint32_t cnt = std::min<uint32_t>(pw, hg1 - g);
-        pass_tasks[npass_t++] = SectionTask{pass ? first_extra[i] + (int)pass - 1 : i, (int32_t)g, (int32_t)cnt, 0};
+    for (uint32_t pass = 0; pass < f.num_passes; pass++) {
+      // Sections go to lanes in order of their byte size (the TOC has it), largest first: a wavefront runs until its longest
+      // section ends, so lanes of similar length finish together (the sum over wavefronts of their longest lane - the
+      // wave-instructions of the launch - nearly halves for 4K frames, whose sections spread 1 : 2.2 around the mean), and the
+      // longest sections start first.  Slot j of the (image, pass) decodes group hf_order[j]; tasks index slots.
+      DevImage& rec = pass ? imgs[(size_t)first_extra[i] + pass - 1] : d;
+      const size_t order_off = pass ? l.extra[pass - 1].hf_order : l.hf_order;
+      uint32_t* order = (uint32_t*)(h_blob + order_off);
+      const size_t sec0 = f.single ? 0 : 2 + (size_t)f.nlf + (size_t)pass * f.ng;
+      for (uint32_t g = hg0; g < hg1; g++) order[g - hg0] = g;
+      if (!f.single)
+        std::stable_sort(order, order + (hg1 - hg0), [&](uint32_t a, uint32_t b) { return f.sec_size[sec0 + a] > f.sec_size[sec0 + b]; });
+      rec.hf_order = (const uint32_t*)(d_blob + order_off);
+      for (uint32_t j = 0; j < hg1 - hg0; j += pw) {
+        const uint32_t cnt = std::min<uint32_t>(pw, hg1 - hg0 - j);
+        pass_tasks[npass_t++] = SectionTask{pass ? first_extra[i] + (int)pass - 1 : i, (int32_t)j, (int32_t)cnt, 0};
         const size_t lanes = (size_t)((cnt + 3) & ~3u) * HfLaneLdsBytes(32);   // the kernel lays its per-lane arrays out for the task's lanes
         lds_hf = std::max(lds_hf, hf_table_bytes(f) + lanes);
         lds_hf_lanes = std::max(lds_hf_lanes, lanes);
       }
+    }
     const uint32_t ag0 = (uint32_t)(d.band_y0 / kGroupDim) * f.xg, ag1 = (uint32_t)((d.band_y1 + kGroupDim - 1) / kGroupDim) * f.xg;
     if (d.has_alpha)
       for (uint32_t g = ag0; g < ag1; g += per_alpha_wg)
@@ -1066,6 +1081,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   }
   const int hf_ring = 32;   // words of the per-lane bit window
   const size_t kLdsMax = 150 * 1024;
+  // experiment knobs: code tables of the entropy kernels read from global memory (L1 / L2) instead of LDS copies
+  if (Knob("JXLHIP_HF_GLOBAL")) lds_hf = kLdsMax + 1;
+  if (Knob("JXLHIP_ALPHA_GLOBAL")) lds_alpha = kLdsMax + 1;
+  if (Knob("JXLHIP_LF_GLOBAL")) lds_lf = kLdsMax + 1;
   memcpy(h_blob + off_imgs, imgs.data(), sizeof(DevImage) * imgs.size());
   d_imgs = (DevImage*)(d_blob + off_imgs);
   // ---- 4. enqueue: LF chain on s_lf, everything that needs the block layout on the main stream
@@ -1117,18 +1136,24 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
   }
   Mark("main_start", stream, 2);
+  // experiment knob: the pixel stages behind the HF chain on ITS stream (no overlap between a batch's pixels and the next batch's HF decode)
+  hipStream_t s_pix = (Knob("JXLHIP_PIX_ON_HF") && s_hf != stream) ? s_hf : stream;
   for (int c0 = 0; c0 < n; c0 += pixel_chunk) {
     const int cnt = std::min(pixel_chunk, n - c0);
     if (!(skip_stages & 8))
-    LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, stream);
-    Mark("reconstruct", stream, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
-    LaunchExpandCoefficients(d_imgs + c0, cnt, false, max_tiles, stream);
-    LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, stream);
-    Mark("reconstruct_generic", stream, 2);
-    if (debug_taps) { HIP_OK(hipStreamSynchronize(stream)); CopyPlaneTap(1); }
+    LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, s_pix);
+    Mark("reconstruct", s_pix, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
+    LaunchExpandCoefficients(d_imgs + c0, cnt, false, max_tiles, s_pix);
+    LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, s_pix);
+    Mark("reconstruct_generic", s_pix, 2);
+    if (debug_taps) { HIP_OK(hipStreamSynchronize(s_pix)); CopyPlaneTap(1); }
     if (!(skip_stages & 16))
-    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, stream);
-    Mark("filters+output", stream, 2);
+    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, s_pix);
+    Mark("filters+output", s_pix, 2);
+  }
+  if (s_pix != stream) {
+    HIP_OK(hipEventRecord(S.hf_done, s_pix));
+    HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
   }
   if (nmod_t) {
     // Modular (lossless) frames of the batch; they depend on nothing but the upload

@@ -149,6 +149,7 @@ struct DevImage {
   ChanDesc* alpha_desc;     // per group
   uint32_t* blk_list;       // per group: 1024 x 2 words, varblocks in decode order (hf_blocklist_kernel)
   uint32_t* blk_count;      // per group
+  const uint32_t* hf_order; // slot -> group of this (image, pass): the decoded groups sorted by section size, largest first (hf_decode_kernel)
   uint64_t* grp_bitpos;     // per group: codestream bit position after the HF tokens (~0 = failed)
   // Progressive frames: every pass after the first is a record of its own after the batch's images (same block layout, its own code,
   // coefficient orders, entry lists and sections); next_pass chains them.  The alpha stream follows the HF tokens of the LAST pass.

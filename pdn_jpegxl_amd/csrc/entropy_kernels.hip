@@ -1379,7 +1379,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
   const int si = (threadIdx.x >> 6) * per_wave + (threadIdx.x & 63);
   if (si >= task.count || si >= nslots) return;
   JXL_LDS uint8_t* const col = nzcol + si;   // col[(c * 32 + x) * nslots]
-  const int g = task.first + si;
+  const int g = im.hf_order[task.first + si];   // lanes in order of section size (see the task table in decoder.cc)
   const int sec = im.single ? 0 : im.hf_sec_base + g;
   const uint64_t sec_bits = im.single ? im.hf_start_bits : im.sec_off[sec] * 8;
   Bits b;

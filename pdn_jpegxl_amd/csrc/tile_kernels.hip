@@ -1,12 +1,15 @@
-// LDS-tiled pixel stages (gfx950).
+// LDS-tiled and register-streaming pixel stages (gfx950).
 //
-//   recon_tile_kernel    one workgroup per 64x64 tile: dequantisation (+ chroma from luma), LF->LLF, both IDCT passes
-//                        all in LDS (tiles with special 8x8 transforms or blocks > 64 go to the generic kernels).  HBM traffic: 12 B/px in (int32 coefficients),
-//                        12 B/px out (f32 XYB).  Tiles that hold part of a varblock larger than the tile are appended to a
-//                        per-image list and handled by the generic (unfused, any-size) kernels of kernels.hip.
-//   filter_tile_kernel   Gaborish / EPF stage on a 64x32 tile + halo staged in LDS (mirrored at the frame edge exactly like
-//                        the unfused stage).  The LAST enabled stage of an image converts XYB -> sRGB u8 and merges alpha
-//                        instead of writing float planes.
+//   recon_tile_kernel     one workgroup per 64x64 tile, all three channels: the sparse entry lists hf_decode_kernel wrote (one 32-bit
+//                         entry per non-zero coefficient) are dequantised and scattered into three zeroed LDS tiles, chroma from
+//                         luma added from the same luma entries, LF -> LLF, both IDCT passes in place (16x16 sub-blocks of varblocks
+//                         >= 16 points on v_mfma_f32_16x16x4_f32), f32 XYB out (12 B/px).  Tiles that hold part of a varblock larger
+//                         than the tile, a special 8x8 transform or a progressive frame go to a per-image list for the generic
+//                         (unfused, any-size) kernels of kernels.hip.
+//   filter_stream_kernel  Gaborish + one / two EPF iterations + XYB -> output samples in one register-streaming kernel (DPP row shifts).
+//   filter_tile_kernel    one Gaborish / EPF stage on a 64x32 tile + halo staged in LDS (mirrored at the frame edge); the LAST
+//                         enabled stage of an image converts XYB -> output samples and merges alpha.  Used for what the streaming
+//                         kernel does not cover.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "dev_types.h"
@@ -48,8 +51,6 @@ __device__ __forceinline__ int Mirror(int v, int n) {
   return v;
 }
 
-// v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
-// * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
 // v^(1/2.4) through the hardware log2 / exp2 (v_log_f32, v_exp_f32: about 1 ulp each, i.e. < 1e-3 of an 8-bit step after the
 // * 255) instead of the ~50-instruction powf: the colour conversion was 46 % of the fused filter kernel.
 __device__ __forceinline__ float SrgbOetfT(float v) {
@@ -181,79 +182,56 @@ __device__ __forceinline__ float DequantBias(int32_t v, float qb, float qb3) {
 }
 typedef int __attribute__((ext_vector_type(4))) I4v;
 
-// One sweep of the scatter: entries [0, total) of the tile's (block, channel) lists, found through the exclusive prefix `pre` over
-// the tile's 64 cells (only origin cells have entries).  Every entry is one non-zero quantised coefficient: its scan position k
-// selects {stored index, weight} from the per-table scan list, the stored index gives the coefficient's place in the varblock.
-// mul: channel multiplier (and, for the luma sweep of a chroma channel, the chroma-from-luma factor).  Adds into the zeroed tile
-// with ds_add_f32: a position receives at most one addend per sweep, two sweeps commute.
-__device__ __forceinline__ void ScatterSweep(float* cfc, const uint32_t* pre, const uint32_t* start, const uint32_t total, const uint32_t* entries,
-                                             const U32x2* const* csc, const uint32_t* cnq, const uint32_t* cmeta, const float* cscale,
-                                             int chan, float qb, float qb3, float mul, int tid) {
-  for (uint32_t e0 = 0; e0 < total; e0 += 512) {
-    uint32_t j[2], ent[2];
-    bool on[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const uint32_t e = e0 + u * 256 + tid;
-      on[u] = e < total;
-      uint32_t jj = 0;
-#pragma unroll
-      for (int step = 32; step; step >>= 1) if (pre[jj + step] <= e) jj += step;
-      j[u] = jj;
-      ent[u] = on[u] ? entries[start[jj] + (e - pre[jj])] : 0u;
-    }
-    U32x2 se[2];
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const uint32_t k = ent[u] & 0xFFFFu, nq = cnq[j[u]];
-      on[u] = on[u] && k < nq;   // a list that a failed section left half-written must not index past the table
-      se[u] = csc[j[u]][(size_t)chan * nq + (on[u] ? k : 0u)];
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      if (!on[u]) continue;
-      const uint32_t meta = cmeta[j[u]];
-      const uint32_t lng = meta & 15, p = se[u].x;
-      const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
-      const uint32_t ky = (meta & 16) ? cc : r, kx = (meta & 16) ? r : cc;
-      const int32_t v = (int32_t)ent[u] >> 16;
-      const float o = DequantBias(v, qb, qb3) * (cscale[j[u]] * mul) * __uint_as_float(se[u].y);
-      if (ky < 64 && kx < 64) atomicAdd(&cfc[((j[u] >> 3) * 8 + ky) * kLP + (j[u] & 7) * 8 + kx], o);
-    }
-  }
-}
+// The scatter: every entry of the tile's (block, channel) lists is one non-zero quantised coefficient; its scan position k selects
+// {stored index, weight} from the per-table scan list, the stored index gives the coefficient's place in the varblock.  The lists of
+// the three channels are walked as ONE range [0, T_y + T_x + T_b) by all 768 threads (a 4K frame has about 270 luma and 30 + 30
+// chroma entries per tile: one trip).  An entry's cell comes from a binary search over the exclusive prefix of its channel's
+// per-cell entry counts (only origin cells have entries).  A luma entry is also what chroma from luma adds to X and B - the IDCT is
+// linear and the tile is inside one 64x64 chroma-from-luma tile - so it is added three times (dequantised once) instead of the X
+// and B workgroups of the previous version walking and dequantising the luma list again.  Adds into the zeroed tiles with
+// ds_add_f32: a position receives at most one own addend and one luma addend, two addends commute, so the sums do not depend on
+// the order the lanes arrive in.
+constexpr int kTileF = kTS * kLP;   // floats of one channel's tile
 
-__global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
+// One workgroup per 64x64 tile, all three channels (12 wavefronts: team t = wave / 4 owns channel Y, X, B; inside a team the four
+// wavefronts split the tile as the one-channel version did): dequantisation with chroma from luma, LF -> LLF, both IDCT passes in
+// LDS.  Tiles that hold part of a varblock larger than the tile, or a special 8x8 transform, are appended to a per-image list for
+// the generic kernels.
+//   * three 64x65 tiles: both IDCT passes run IN PLACE.  The vertical pass gives a wavefront the column stripe [16w, 16w+16) of
+//     its channel (everything a stripe's outputs depend on lies in the same columns), the horizontal pass the row band
+//     [16w, 16w+16); a wavefront fetches all its operands before it stores, so no workgroup barrier is needed inside a pass, and
+//     the copy-out of a row band needs only that wavefront.
+//   * the per-cell set-up (cell info, scale, table pointers, entry-list prefixes of the three channels) is done once per tile by
+//     wavefront 0; LLF of channel t is computed by the first wavefront of team t with lane shuffles while the others scatter.
+//   * 1 / v through v_rcp_f32 (1 ulp; the term is a bias correction <= 0.15 / |v|).
+__global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
                                                              const float* llf_scale) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
-  float* cfc = (float*)smem_raw;                       // kTS * kLP   coefficients -> columns done -> pixels
-  float* B816 = cfc + kTS * kLP;                       // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
+  float* cfc3 = (float*)smem_raw;                      // 3 * kTileF   coefficients -> columns done -> pixels; team order Y, X, B
+  float* B816 = cfc3 + 3 * kTileF;                     // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
   float* cscale = B816 + 320;                          // 64   per cell: inv_global_scale / raw quant of its varblock
   uint32_t* ci = (uint32_t*)(cscale + 64);             // 64   cell info
   uint32_t* cmeta = ci + 64;                           // 64   log2 of the table pitch | transposed << 4
   uint32_t* cnq = cmeta + 64;                          // 64   entries per channel of the cell's dequant table
-  uint32_t* cpre = cnq + 64;                           // 64   exclusive prefix of the entry counts, own channel ...
-  uint32_t* cstart = cpre + 64;                        // 64   ... and where each origin cell's entries start in the group's list
-  uint32_t* cpre_y = cstart + 64;                      // 64   the same for the luma lists (chroma from luma)
-  uint32_t* cstart_y = cpre_y + 64;                    // 64
-  uint32_t* ctot = cstart_y + 64;                      // 2 (+2 pad)  totals
+  uint32_t* cpre = cnq + 64;                           // 3 x 64   exclusive prefix of the entry counts per team ...
+  uint32_t* cstart = cpre + 3 * 64;                    // 3 x 64   ... and where each origin cell's entries start in the group's list
+  uint32_t* ctot = cstart + 3 * 64;                    // 4    totals per team
   const U32x2** csc = (const U32x2**)(ctot + 4);       // 64   scan list of the cell's quant table
   const DevImage& im = imgs[blockIdx.y];
-  const int tile = blockIdx.x / 3, cidx = blockIdx.x % 3;
+  const int tile = blockIdx.x;
   if (tile >= im.wt * im.ht) return;
   const int tid = threadIdx.x;
   const int tx = tile % im.wt, ty = tile / im.wt;
   if (ty < im.dec_gy0 * 4 || ty >= im.dec_gy1 * 4) return;   // outside the decoded band (4 tile rows per group row)
-  const int c = cidx == 0 ? 1 : (cidx == 1 ? 0 : 2);
+  const int wave = tid >> 6, lane = tid & 63, team = wave >> 2, tw = wave & 3;
+  const int c = team == 0 ? 1 : (team == 1 ? 0 : 2);          // channel of this wavefront's team
   const int wp = im.wp, hp = im.hp;
-  // the tile starts as zeros: only non-zero coefficients exist in the entry lists
+  // the tiles start as zeros: only non-zero coefficients exist in the entry lists
   {
-    float4* z = (float4*)cfc;
-    for (int i = tid; i < kTS * kLP / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* z = (float4*)cfc3;
+    for (int i = tid; i < 3 * kTileF / 4; i += 768) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   int bad = 0;
-  uint32_t info0 = 0;
-  float lfv = 0.f;
   if (tid < 64) {
     const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
     const bool inside = cx < im.w8 && cy < im.h8;
@@ -261,14 +239,10 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     const size_t ncells = (size_t)im.w8 * im.h8;
     const uint32_t info_g = im.cellinfo[cell_g];
     const uint32_t rq_g = im.rawq[cell_g];
-    const float lf_g = im.lf_final[c][cell_g];
-    const U32x2 blk_g = im.cblk[(size_t)c * ncells + cell_g];
-    U32x2 blk_y = blk_g;
-    if (c != 1) blk_y = im.cblk[ncells + cell_g];
+    U32x2 blk[3];
+    blk[0] = im.cblk[ncells + cell_g]; blk[1] = im.cblk[cell_g]; blk[2] = im.cblk[2 * ncells + cell_g];   // team order: Y, X, B
     const uint32_t info = inside ? info_g : 0u;
     const uint32_t rqv = inside ? rq_g : 1u;
-    lfv = inside ? lf_g : 0.f;
-    info0 = info;
     const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
     if (inside) {
       if (!(info >> 31)) bad = 1;
@@ -290,33 +264,48 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     csc[tid] = im.scan[q];
     // entry lists of the varblocks that start in this tile; a list a failed section left unwritten is treated as empty
     const bool origin = valid && ix == 0 && iy == 0;
-    uint32_t n_own = origin ? blk_g.y : 0u, n_y = (origin && c != 1) ? blk_y.y : 0u;
-    if (n_own > 65536u || blk_g.x > kGroupEntriesCap - n_own) n_own = 0;
-    if (n_y > 65536u || blk_y.x > kGroupEntriesCap - n_y) n_y = 0;
-    uint32_t s_own = n_own, s_y = n_y;   // inclusive scans over the wavefront
+    uint32_t cnt[3], sum[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      cnt[t] = origin ? blk[t].y : 0u;
+      if (cnt[t] > 65536u || blk[t].x > kGroupEntriesCap - cnt[t]) cnt[t] = 0;
+      sum[t] = cnt[t];   // inclusive scans over the wavefront
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const uint32_t a = (uint32_t)__shfl_up((int)s_own, d), bq = (uint32_t)__shfl_up((int)s_y, d);
-      if (tid >= d) { s_own += a; s_y += bq; }
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        const uint32_t a = (uint32_t)__shfl_up((int)sum[t], d);
+        if (tid >= d) sum[t] += a;
+      }
     }
-    cpre[tid] = s_own - n_own; cstart[tid] = blk_g.x;
-    cpre_y[tid] = s_y - n_y; cstart_y[tid] = blk_y.x;
-    if (tid == 63) { ctot[0] = s_own; ctot[1] = s_y; }
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      cpre[t * 64 + tid] = sum[t] - cnt[t];
+      cstart[t * 64 + tid] = blk[t].x;
+      if (tid == 63) ctot[t] = sum[t];
+    }
+  } else if (tid < 64 + 320) {
+    B816[tid - 64] = basis_all[tid - 64];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
   }
-  for (int i = tid; i < 320; i += 256) B816[i] = basis_all[i];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
   if (im.num_passes > 1) bad = 1;   // progressive frames: the passes' entries are summed as integers first (expand kernels, generic path)
   if (__syncthreads_or(bad)) {
-    if (tid == 0 && cidx == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
+    if (tid == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
     return;
   }
   const float* const Bl = basis_all;
-  // ---- LLF (wavefront 0): lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples, by lane shuffles
-  if (tid < 64) {
-    const uint32_t info = info0;
+  float* const cfc = cfc3 + team * kTileF;   // this team's tile
+  // ---- LLF (first wavefront of each team): lowest cx*cy coefficients of every varblock = scaled 2-D DCT of its LF samples, by lane shuffles
+  if (tw == 0) {
+    const int cxg = tx * 8 + (lane & 7), cyg = ty * 8 + (lane >> 3);
+    const bool inside = cxg < im.w8 && cyg < im.h8;
+    const float lf_g = im.lf_final[c][(size_t)min(cyg, im.h8 - 1) * im.w8 + min(cxg, im.w8 - 1)];
+    const float lfv = inside ? lf_g : 0.f;
+    const uint32_t info = ci[lane];
     const bool valid = info >> 31;
     const int ix = (info >> 8) & 31, iy = (info >> 13) & 31, lcx = (info >> 18) & 7, lcy = (info >> 21) & 7;
     const int cx = 1 << lcx, cy = 1 << lcy;
-    const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
+    const int ox = (lane & 7) - ix, oy = (lane >> 3) - iy;
     const float* Bx = basis_small + (cx * cx - 1) / 3 + ix * cx;
     const float* By = basis_small + (cy * cy - 1) / 3 + iy * cy;
     float bx[8], byv[8];
@@ -326,40 +315,67 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
     float row = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const float v = __shfl(lfv, (tid - ix + k) & 63);
+      const float v = __shfl(lfv, (lane - ix + k) & 63);
       if (valid && k < cx) row += v * bx[k];
     }
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const float v = __shfl(row, ((oy + k) * 8 + (tid & 7)) & 63);
+      const float v = __shfl(row, ((oy + k) * 8 + (lane & 7)) & 63);
       if (valid && k < cy) acc += v * byv[k];
     }
-    if (valid) cfc[(oy * 8 + iy) * kLP + ox * 8 + ix] = acc * sc;
+    // (an add like the entries': a custom coefficient order may send an entry to an LLF position, and sums do not depend on who comes first)
+    if (valid) atomicAdd(&cfc[(oy * 8 + iy) * kLP + ox * 8 + ix], acc * sc);
   }
   // ---- dequantisation (+ chroma from luma) of the non-zero coefficients, scattered to their places
   {
     const size_t tile_cfl = (size_t)ty * im.wt + tx;
-    const float cfl = c == 1 ? 0.f : (c == 0 ? im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor
-                                              : im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor);
-    const float dm = c == 0 ? im.x_dm : (c == 1 ? 1.0f : im.b_dm);
+    const float cfl_x = im.base_x + (float)im.ytox[tile_cfl] * im.inv_color_factor;
+    const float cfl_b = im.base_b + (float)im.ytob[tile_cfl] * im.inv_color_factor;
     // the tile's group (four tiles per group side)
     const uint32_t* entries = im.centries + (size_t)((ty >> 2) * im.xg + (tx >> 2) - im.centries_g0) * kGroupEntriesCap;
-    ScatterSweep(cfc, cpre, cstart, ctot[0], entries, csc, cnq, cmeta, cscale, c, im.qbias[c], im.qbias[3], dm, tid);
-    if (c != 1 && cfl != 0.f) ScatterSweep(cfc, cpre_y, cstart_y, ctot[1], entries, csc, cnq, cmeta, cscale, 1, im.qbias[1], im.qbias[3], cfl, tid);
+    const uint32_t t0 = ctot[0], t01 = t0 + ctot[1], total = t01 + ctot[2];
+    const float qb3 = im.qbias[3];
+    for (uint32_t e = (uint32_t)tid; e < total; e += 768) {
+      const uint32_t t = (e >= t0) + (e >= t01);                     // team of this entry: 0 Y, 1 X, 2 B
+      const uint32_t el = e - (t == 0 ? 0u : (t == 1 ? t0 : t01));
+      const uint32_t* pre = cpre + t * 64;
+      uint32_t j = 0;
+#pragma unroll
+      for (int step = 32; step; step >>= 1) if (pre[j + step] <= el) j += step;
+      const uint32_t ent = entries[cstart[t * 64 + j] + (el - pre[j])];
+      const uint32_t k = ent & 0xFFFFu, nq = cnq[j];
+      if (k >= nq) continue;   // a list that a failed section left half-written must not index past the table
+      const int chan = t == 0 ? 1 : (t == 1 ? 0 : 2);
+      const U32x2 se = csc[j][(size_t)chan * nq + k];
+      const uint32_t meta = cmeta[j];
+      const uint32_t lng = meta & 15, p = se.x;
+      const uint32_t r = p >> lng, cc = p & ((1u << lng) - 1);
+      const uint32_t ky = (meta & 16) ? cc : r, kx = (meta & 16) ? r : cc;
+      if (ky >= 64 || kx >= 64) continue;
+      const int32_t v = (int32_t)ent >> 16;
+      const float dm = t == 0 ? 1.0f : (t == 1 ? im.x_dm : im.b_dm);
+      const float o = DequantBias(v, im.qbias[chan], qb3) * (cscale[j] * dm) * __uint_as_float(se.y);
+      const uint32_t at = ((j >> 3) * 8 + ky) * kLP + (j & 7) * 8 + kx;
+      atomicAdd(&cfc3[t * kTileF + at], o);
+      if (t == 0) {   // chroma from luma: X += cfl_x * Y, B += cfl_b * Y on the dequantised luma coefficient
+        if (cfl_x != 0.f) atomicAdd(&cfc3[kTileF + at], o * cfl_x);
+        if (cfl_b != 0.f) atomicAdd(&cfc3[2 * kTileF + at], o * cfl_b);
+      }
+    }
   }
   __syncthreads();
-  const int wave = tid >> 6, lane = tid & 63, l16 = tid & 15, lq = lane >> 4;
+  const int l16 = tid & 15, lq = lane >> 4;
   // ---- vertical pass, in place: wavefront = column stripe.  Matrix cores for every 16x16 sub-block that lies inside a varblock
   // of at least 16 points both ways: Basis_R^T (16 x R) * coefficients (R x 16) by v_mfma_f32_16x16x4_f32 (exact f32, the same
   // k-ordered fma chain as the VALU path).  Lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15], owns D[4 * (l >> 4) + r][l & 15].
   {
     F4 acc[4];
     bool m[4];
-    const int x0 = wave * 16;
+    const int x0 = tw * 16;
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
-      const uint32_t inf = ci[rb * 16 + wave * 2];
+      const uint32_t inf = ci[rb * 16 + tw * 2];
       m[rb] = MfmaSubBlock(inf);   // wave-uniform
       if (m[rb]) {
         const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
@@ -408,10 +424,10 @@ __global__ __launch_bounds__(256, 6) void recon_tile_kernel(const DevImage* imgs
   {
     F4 acc[4];
     bool m[4];
-    const int y0 = wave * 16;
+    const int y0 = tw * 16;
 #pragma unroll
     for (int cs = 0; cs < 4; cs++) {
-      const uint32_t inf = ci[wave * 16 + cs * 2];
+      const uint32_t inf = ci[tw * 16 + cs * 2];
       m[cs] = MfmaSubBlock(inf);
       if (m[cs]) {
         const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
@@ -787,8 +803,11 @@ __global__ void out_only_kernel(const DevImage* imgs) {
 
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, hipStream_t s) {
-  const size_t lds = (size_t)(kTS * kLP + 320 + 64 * 8 + 4 + 128) * 4;   // tile, B816, eight per-cell words, totals, per-cell scan-list pointers
-  hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles * 3, nimg), dim3(256), lds, s, imgs, basis_all, basis_small, llf_scale);
+  // three tiles, B816, four per-cell words + 2 x 3 prefix words per cell, totals, per-cell scan-list pointers
+  const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128) * 4;
+  static bool raised = false;
+  if (!raised) { (void)hipFuncSetAttribute((const void*)recon_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
+  hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale);
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,

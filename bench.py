@@ -9,6 +9,13 @@ Workloads (--workload):
             shard with no data-path collective (DESIGN.md "Multi-GPU").
   16k-bands (configs[2]) one step = ONE 16384x16384 RGBA8 lossy frame decoded by all ranks together: every rank decodes its band of
             256x256-group rows and the bands are gathered with one RCCL all_gather over xGMI.  Strong scaling.
+  4k-lossless (configs[4]) one step = one 3840x2160 Modular lossless frame (Squeeze + weighted predictor: the stream kind the config
+            names; two more kinds and the product encoder's own stream are timed beside it) decoded from HBM-resident bytes, checked
+            bit-exact against the source picture.
+  4k-encode (configs[3]) one step = one SaveImage of the 3840x2160 picture (lossy VarDCT, distance 1.0, effort 7) through the C-ABI.
+  512-abi   (configs[0]) one step = one LoadImage of a 512x512 RGBA8 lossy file through the C-ABI (host buffers, callbacks): the call
+            the reference's plugin makes, on the shape where a GPU has the least to offer.
+  With --gpus N these three run as N independent replicas ("replicas only": one frame does not shard).
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts N ranks itself (torch.distributed.run, one
 process per GPU, before this process touches a GPU) and exits with their code.
@@ -190,7 +197,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["4k", "16k-bands"], default=os.environ.get("JXLHIP_BENCH_WORKLOAD", "4k"))
+    ap.add_argument("--workload", choices=["4k", "16k-bands", "4k-lossless", "4k-encode", "512-abi"], default=os.environ.get("JXLHIP_BENCH_WORKLOAD", "4k"))
     ap.add_argument("--batch", type=int, default=int(os.environ.get("JXLHIP_BENCH_BATCH", "384")))
     ap.add_argument("--frame-size", type=int, default=16384, help="side of the 16k-bands frame (smaller for rehearsals)")
     ap.add_argument("--lane-stride", type=int, default=0)
@@ -199,7 +206,7 @@ def main():
     ap.add_argument("--sync-steps", action="store_true", help="synchronise after every step (no cross-batch overlap)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 20 if args.workload == "4k" else 10
+        args.steps = {"4k": 20, "16k-bands": 10, "4k-lossless": 5, "4k-encode": 10, "512-abi": 30}[args.workload]
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
 
@@ -239,12 +246,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    # what every rank saw: the driver's scaling record can check that N ranks really ran on N devices over RCCL
+    me = {"rank": rank, "local_rank": local_rank, "device": torch.cuda.current_device(), "device_name": torch.cuda.get_device_name(),
+          "world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else "none"),
+          "visible_devices": torch.cuda.device_count()}
+    ranks = [me]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
     dec = api.Decoder(local_rank)
     dec.set_option("lane_stride", args.lane_stride)
     if args.workload == "16k-bands":
         line = run_bands(args, dec, rank, world, rehearsal, coll_dev, fence, max_over_ranks)
-    else:
+    elif args.workload == "4k":
         line = run_4k(args, dec, rank, world, coll_dev, fence, max_over_ranks)
+    else:
+        line = run_side(args, dec, rank, world, fence, max_over_ranks)
+    if rank == 0 and line is not None:
+        line["ranks"] = ranks
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -325,6 +344,16 @@ def run_4k(args, dec, rank, world, coll_dev, fence, max_over_ranks):
         dec.decode_batch(files[:1], dev_out[:1], dev_in[:1], synchronize=True)
         lat.append((time.perf_counter() - t1) * 1e3)
     lat_stages = dec.stage_times()
+    # ... and what the reference's plugin calls: LoadImage through the C-ABI, host buffers in and out, callbacks (one image per
+    # synchronous call, JpegXLLoad.cs:30-69).  The first call of a thread pays for the decoder's workspaces: reported as "cold".
+    t1 = time.perf_counter()
+    api.load_image(distinct[0])
+    abi_cold = (time.perf_counter() - t1) * 1e3
+    abi = []
+    for _ in range(4):
+        t1 = time.perf_counter()
+        api.load_image(distinct[0])
+        abi.append((time.perf_counter() - t1) * 1e3)
     if rank != 0:
         return None
     mp = W * H / 1e6
@@ -353,10 +382,168 @@ def run_4k(args, dec, rank, world, coll_dev, fence, max_over_ranks):
         "stage_ms_note": "HIP-event time per stage on its own stream; three streams overlap, so the stages add up to more than ms_per_step",
         "host_submit_ms_per_batch": round(min(host_ms), 3),
         "single_image": {"latency_ms": round(min(lat), 3), "mp_per_s": round(mp / (min(lat) * 1e-3), 2),
-                         "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()}},
+                         "stage_ms": {k: round(v, 4) for k, v in lat_stages.items()},
+                         "through_abi_ms": {"warm": round(min(abi), 3), "cold_first_call_of_the_thread": round(abi_cold, 3),
+                                            "mp_per_s_warm": round(mp / (min(abi) * 1e-3), 2),
+                                            "note": "LoadImage with host buffers and callbacks (PCIe both ways included); cold = first call of a thread "
+                                                    "in a process whose HIP context exists: workspace allocation, not decode work"}},
     }
+    if line["roofline"]["traffic"] is not None:
+        line["roofline"]["traffic_note"] = "PMC bytes (2*FETCH_SIZE + WRITE_SIZE) from the newest committed profiles/r*_pmc_traffic.json, profiled at batch 16 and scaled to this launch's images; not measured in this run"
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(distinct, W, H)
+    return line
+
+
+def _oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    try:
+        O.use(O.build_native())
+        return O, "-O3 -march=native, built on this box"
+    except Exception as e:
+        return O, "portable -O2 build (native build failed: %s)" % str(e)[:80]
+
+
+def _cpu_side(fn, unit_mp, what, seconds_budget=12.0):
+    """cpu_baseline of a side workload: fn(threads) runs the oracle once; thread count probed, bounded sample, median."""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({t for t in (1, 8, 16, 32, 64) if t <= usable})
+    probe = {}
+    for t in cands:
+        t0 = time.perf_counter()
+        fn(t)
+        probe[t] = time.perf_counter() - t0
+    threads = min(probe, key=probe.get)
+    times = []
+    t_end = time.perf_counter() + seconds_budget
+    while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 12):
+        t0 = time.perf_counter()
+        fn(threads)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return {"value": round(unit_mp / med, 3), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": "%d runs of %s, %d threads (the fastest of %s), median" % (len(times), what, threads, cands),
+            "host_cores_usable": usable, "ms": round(med * 1e3, 2)}
+
+
+def _roof(stage_ms, alg_bytes, kernel_of):
+    dom = max(stage_ms, key=stage_ms.get)
+    ms = stage_ms[dom]
+    ach = alg_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": kernel_of.get(dom, dom), "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 6),
+            "traffic": None, "algorithmic_bytes_per_launch": int(alg_bytes), "launch_ms": round(ms, 4), "stage": dom,
+            "note": "dominant stage of one call (HIP events on the stage's stream); one call = one launch of each of its kernels"}
+
+
+def run_side(args, dec, rank, world, fence, max_over_ranks):
+    """configs[0], [3], [4]: one frame per step, N replicas when --gpus N."""
+    import numpy as np
+    import torch
+    from pdn_jpegxl_amd import api
+    from pdn_jpegxl_amd.synth import synth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import bench_inputs
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    extra = {}
+    if args.workload == "4k-lossless":
+        streams, rgb = bench_inputs.lossless_4k_streams()
+        streams = dict(streams)
+        streams["product-encoder (YCoCg-R + gradient, row-static)"] = api.save_image(np.ascontiguousarray(np.dstack([rgb[..., 2], rgb[..., 1], rgb[..., 0], np.full(rgb.shape[:2], 255, np.uint8)])), lossless=True)
+        main_key = "squeeze+weighted"
+        H, W = rgb.shape[:2]
+        results = {}
+        for key, data in streams.items():
+            info = api.peek(data)
+            out = torch.empty(info.width * info.height * info.num_channels, dtype=torch.uint8, device="cuda")
+            src = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+            src[: len(data)] = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+            run = lambda: dec.decode_batch([data], [out.data_ptr()], [src.data_ptr()], synchronize=True)
+            run()
+            got = out.cpu().numpy().reshape(info.height, info.width, info.num_channels)
+            assert np.array_equal(got[..., :3], rgb), "lossless decode of %s is not bit-exact" % key
+            k = args.steps if key == main_key else 2
+            for _ in range(args.warmup if key == main_key else 0):
+                run()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                run()
+            fence()
+            ms = max_over_ranks((time.perf_counter() - t0) / k * 1e3)
+            stages = dec.stage_times()
+            api.load_image(data)
+            t1 = time.perf_counter()
+            api.load_image(data)
+            results[key] = {"ms": round(ms, 2), "mp_per_s": round(W * H / 1e3 / ms, 2), "jxl_bytes": len(data), "stage_ms": {n: round(v, 3) for n, v in stages.items()},
+                            "through_abi_ms": round((time.perf_counter() - t1) * 1e3, 2), "bit_exact_vs_source": True}
+        ms = results[main_key]["ms"]
+        metric, workload = "megapixels/sec decode (4K Modular lossless)", "3840x2160 RGB8 Modular lossless (Squeeze + weighted predictor + MA tree), HBM-resident .jxl -> HBM RGB8, bit-exact vs source"
+        roof = _roof({k: v for k, v in results[main_key]["stage_ms"].items()}, len(streams[main_key]) + W * H * 3, {"modular": "modular_ans_kernel"})
+        extra["variants"] = results
+        mp = W * H / 1e6
+        if want_cpu:
+            O, build = _oracle()
+            extra["cpu_baseline"] = _cpu_side(lambda t: O.decode(streams[main_key], num_threads=t), mp, "the CPU oracle decoding the same stream (%s)" % build)
+    elif args.workload == "4k-encode":
+        img = synth(3840, 2160, 2)
+        bgra = np.ascontiguousarray(img[..., [2, 1, 0, 3]])
+        H, W = img.shape[:2]
+        run = lambda: api.save_image(bgra, distance=1.0, effort=7)
+        data = run()
+        for _ in range(args.warmup):
+            run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            data = run()
+        fence()
+        ms = max_over_ranks((time.perf_counter() - t0) / args.steps * 1e3)
+        stages = api.last_save_stage_times()
+        back = api.load_image(data).pixels
+        err = np.abs(back.astype(np.int32) - img.astype(np.int32))
+        metric, workload = "megapixels/sec encode (4K lossy VarDCT)", "3840x2160 BGRA8 -> lossy VarDCT .jxl (distance 1.0, effort 7) through SaveImage (host buffer in, Write callbacks out: PCIe included, the ABI has no device-resident form)"
+        roof = _roof(stages, W * H * 4 + len(data), {})
+        extra.update({"jxl_bytes": len(data), "bits_per_pixel": round(len(data) * 8 / (W * H), 3), "stage_ms": {n: round(v, 3) for n, v in stages.items()},
+                      "roundtrip_mean_abs_error_u8": round(float(err[..., :3].mean()), 3), "alpha_exact": bool((back[..., 3] == img[..., 3]).all())})
+        mp = W * H / 1e6
+        if want_cpu:
+            O, build = _oracle()
+            extra["cpu_baseline"] = _cpu_side(lambda t: O.encode(img, distance=1.0, num_threads=t), mp, "the CPU oracle encoding the same picture, same settings (%s)" % build)
+    else:   # 512-abi
+        data, img = bench_inputs.lossy_512()
+        H, W = img.shape[:2]
+        run = lambda: api.load_image(data)
+        t1 = time.perf_counter()
+        got = run()
+        cold = (time.perf_counter() - t1) * 1e3
+        for _ in range(args.warmup):
+            run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run()
+        fence()
+        ms = max_over_ranks((time.perf_counter() - t0) / args.steps * 1e3)
+        stages = api.last_load_stage_times()
+        metric, workload = "megapixels/sec decode (512x512 lossy, LoadImage)", "512x512 RGBA8 lossy VarDCT (distance 1.0) through LoadImage: host buffers, callbacks, PCIe both ways"
+        roof = _roof(stages, len(data) + W * H * 4, {"hf_decode": "hf_decode_kernel", "lf_ans": "lf_ans_kernel", "alpha_ans": "alpha_ans_kernel"})
+        extra.update({"jxl_bytes": len(data), "stage_ms": {n: round(v, 3) for n, v in stages.items()}, "cold_first_call_ms": round(cold, 2)})
+        mp = W * H / 1e6
+        if want_cpu:
+            O, build = _oracle()
+            ref = O.decode(data).pixels
+            d = np.abs(got.pixels.astype(np.int32) - ref.astype(np.int32))
+            extra["max_abs_diff_vs_oracle_u8"] = int(d.max())
+            extra["cpu_baseline"] = _cpu_side(lambda t: O.decode(data, num_threads=t), mp, "the CPU oracle decoding the same file (%s)" % build, seconds_budget=6.0)
+    if rank != 0:
+        return None
+    line = {"metric": metric, "value": round(world * mp / (ms * 1e-3), 2), "unit": "MP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32" if args.workload == "4k-lossless" else "f32", "data": "synthetic",
+            "config": {"workload": workload, "parallelism": "replicas only (one frame does not shard)" if world > 1 else "one GPU"},
+            "roofline": roof}
+    line.update(extra)
     return line
 
 

@@ -169,7 +169,9 @@ JXLFILETYPEIO_API size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, co
 
 /* Options: "debug_taps" (0/1: keep qcoef / xyb_idct / xyb_filtered stage copies; slow), "lane_stride" (0 = auto,
  * 64 = one section per wavefront ... 1 = one section per lane), "overlap" (0/1: run the LF stage of the next
- * asynchronous batch on a second stream while the previous batch finishes).  Returns 1 if the option exists. */
+ * asynchronous batch on a second stream while the previous batch finishes), "band_first_row" / "band_rows" (>= 0: decode only these
+ * 256-pixel group rows of a lossy frame into a band-sized buffer), "no_direct" / "mod_lanes64" (launch shapes of the vector loops for
+ * small launches as well; same output).  Returns 1 if the option exists and the value is valid (0: refused, nothing changed). */
 JXLFILETYPEIO_API int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value);
 
 /* Timing of the last synchronised batch: milliseconds per named stage (HIP events on the decode stream). */
@@ -178,6 +180,11 @@ JXLFILETYPEIO_API int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** na
 /* Cumulative per-stage time over every batch finished since the last reset (asynchronous batches included). */
 JXLFILETYPEIO_API int32_t jxlhip_stage_totals(JxlHipDecoder* dec, const char** names, float* ms, int32_t capacity, int32_t* batches,
                                               int32_t reset);
+
+/* Device time of the stages of the calling thread's last LoadImage / lossy SaveImage (HIP events on the streams the kernels were
+ * launched on; measurement only: bench.py's single-image and encode workloads read them next to the wall time of the call). */
+JXLFILETYPEIO_API int32_t jxlhip_last_load_stage_times(const char** names, float* ms, int32_t capacity);
+JXLFILETYPEIO_API int32_t jxlhip_last_save_stage_times(const char** names, float* ms, int32_t capacity);
 
 /* Host-only (no GPU): the embedded ICC profile as LoadImage would hand it to setIccProfile (reference Decoder/JxlDecoder.cpp:652-682);
  * returns its size (0: none) and copies up to `capacity` bytes. */

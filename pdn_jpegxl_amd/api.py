@@ -66,7 +66,8 @@ class ImageInfo(C.Structure):
 
 
 EXPORTS = ["GetLibJxlVersion", "LoadImage", "SaveImage", "jxlhip_parse_icc", "jxlhip_decoder_create", "jxlhip_decoder_destroy", "jxlhip_peek",
-           "jxlhip_decode_batch", "jxlhip_finish", "jxlhip_read_plane", "jxlhip_set_option", "jxlhip_stage_times", "jxlhip_stage_totals"]
+           "jxlhip_decode_batch", "jxlhip_finish", "jxlhip_read_plane", "jxlhip_set_option", "jxlhip_stage_times", "jxlhip_stage_totals",
+           "jxlhip_last_load_stage_times", "jxlhip_last_save_stage_times"]
 
 _lib = None
 
@@ -322,10 +323,32 @@ _PLANE_DTYPES = {"lf": np.float32, "lf_quant": np.int32, "cellinfo": np.uint32, 
                  "xyb_idct": np.float32, "xyb_filtered": np.float32}
 
 
+def _last_stage_times(fn_name):
+    L = lib()
+    fn = getattr(L, fn_name)
+    fn.restype = C.c_int32
+    fn.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_float), C.c_int32]
+    names = (C.c_char_p * 32)()
+    ms = (C.c_float * 32)()
+    k = fn(names, ms, 32)
+    return {names[i].decode(): ms[i] for i in range(k)}
+
+
+def last_load_stage_times():
+    """Device time per stage of this thread's last load_image() call (HIP events)."""
+    return _last_stage_times("jxlhip_last_load_stage_times")
+
+
+def last_save_stage_times():
+    """Device time per kernel group of this thread's last lossy save_image() call (HIP events)."""
+    return _last_stage_times("jxlhip_last_save_stage_times")
+
+
 class Decoder:
     """Device-resident batch decoder (jxlhip_* entry points)."""
 
     def __init__(self, device=-1):
+        self._h = None
         self._L = lib()
         err = ErrorInfo()
         self._h = self._L.jxlhip_decoder_create(device, C.byref(err))

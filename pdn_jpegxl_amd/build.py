@@ -10,7 +10,7 @@ LIBNAME = "libJpegXLFileTypeIO_X64.so"
 TEST_LIBNAME = "libjxlhip_selftest.so"   # the product's objects + csrc/selftest.cc: writer self tests for the CPU suite, never shipped
 TEST_SOURCES = ["selftest.cc"]
 SOURCES = ["kernels.hip", "entropy_kernels.hip", "tile_kernels.hip", "encode_kernels.hip", "host_parse.cc", "host_write.cc", "icc.cc", "decoder.cc", "encoder.cc"]
-HEADERS = ["dev_types.h", "dev_util.h", "enc_types.h", "kernels.h", "host_parse.h", "host_write.h", "icc.h", os.path.join("..", "..", "include", "jxlfiletypeio.h")]
+HEADERS = ["dev_types.h", "dev_util.h", "modular_uniform.h", "enc_types.h", "kernels.h", "host_parse.h", "host_write.h", "icc.h", os.path.join("..", "..", "include", "jxlfiletypeio.h")]
 
 
 def lib_path():

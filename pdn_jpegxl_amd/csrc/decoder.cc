@@ -195,8 +195,14 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   // (measured on MI355X, batch 384: stream priorities and CU masks that confine the entropy streams to part of the chip change
   // nothing or lose - the three chains already add up to the chip's capacity)
   HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&stream_lf, hipStreamNonBlocking));
-  HIP_OK(hipStreamCreateWithFlags(&stream_hf, hipStreamNonBlocking));
+  // The entropy chains are latency-bound (a kernel lasts as long as its longest section) and need few wavefronts, but ALL of them at
+  // once: while their workgroups queue behind a pixel kernel's thousands of short ones, an entropy kernel runs in rounds and takes a
+  // multiple of its time.  Their streams get the highest priority, so that their workgroups take the next free slots.
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  const int prio = Knob("JXLHIP_NO_PRIORITY") ? prio_least : prio_greatest;
+  HIP_OK(hipStreamCreateWithPriority(&stream_lf, hipStreamNonBlocking, prio));
+  HIP_OK(hipStreamCreateWithPriority(&stream_hf, hipStreamNonBlocking, prio));
   for (auto& S : slots) {
     HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));
@@ -861,7 +867,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       status_off[i] = l.z_status;
       d.out = f.orientation == 1 ? dev_out[i] : wr + l.orient_tmp;
       auto code_lds_m = [](const HostCode& hc) { return 8 + 8 * hc.alias.size() + 4 * hc.cfg.size() + hc.ctx_map.size(); };
-      lds_mod = std::max(lds_mod, 64 * 128 + (size_t)mod_lanes * mod_rb * 4 + (mod_wp_lds ? (size_t)mod_lanes * 10 * (mod_rb + 2) * 4 : 0) + 16 +
+      // (one section per wavefront with row buffers: three rows and the leaf grid of modular_uniform.h instead of one row per lane)
+      const size_t mod_rows = (mod_lanes == 1 && mod_rb) ? (size_t)3 * mod_rb * 4 + (size_t)kUniGridCells * 16 : (size_t)mod_lanes * mod_rb * 4;
+      lds_mod = std::max(lds_mod, 64 * 128 + mod_rows + (mod_wp_lds ? (size_t)mod_lanes * 10 * (mod_rb + 2) * 4 : 0) + 16 +
                                       sizeof(DevTreeNode) * f.tree.size() + code_lds_m(f.mcode));
       const uint32_t nsec = 1 + f.nlf + f.ng;
       max_mod_groups = std::max<int>(max_mod_groups, (int)nsec);
@@ -1511,6 +1519,11 @@ static JxlHipDecoder* ThreadDecoder() {
   static thread_local std::unique_ptr<JxlHipDecoder> dec;
   if (!dec) dec.reset(new JxlHipDecoder(-1));
   return dec.get();
+}
+
+// Stage times (HIP events) of this thread's last LoadImage: what bench.py reports beside the wall time of the call
+extern "C" JXLFILETYPEIO_API int32_t jxlhip_last_load_stage_times(const char** names, float* ms, int32_t capacity) {
+  try { return jxlhip_stage_times(ThreadDecoder(), names, ms, capacity); } catch (...) { return 0; }
 }
 
 DecoderStatus LoadImage(DecoderCallbacks* cb, const uint8_t* data, size_t size, ErrorInfo* err) {

@@ -210,6 +210,7 @@ struct DevImage {
   uint32_t* status;         // [0] error bits, [1..] debug
 };
 
+constexpr int kUniGridCells = 2048;   // LDS grid (16-byte leaf records) of the one-section-per-wavefront per-sample Modular decoder (modular_uniform.h)
 constexpr int kBinfoInts = 2 * 1024 + 2 * 65536 + 65536 + 65536 + 64;   // ... + prefix sums of the block widths (placement)
 constexpr int kWpLfInts = 10 * (65536 + 2);   // widest channel of an LF group section: the block-info rows
 

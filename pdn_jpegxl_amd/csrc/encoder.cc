@@ -90,6 +90,30 @@ struct PhaseClock {
   }
 };
 
+// Device time of the encoder's kernel groups, always recorded (a pair of HIP events on the group's own stream; the streams overlap,
+// so the groups can add up to more than the call): what bench.py's encode workload reads through jxlhip_last_save_stage_times.
+struct StageMarks {
+  struct M { const char* name; hipEvent_t a, b; };
+  std::vector<M> marks;
+  ~StageMarks() { for (auto& m : marks) { (void)hipEventDestroy(m.a); (void)hipEventDestroy(m.b); } }
+  size_t Begin(const char* name, hipStream_t s) {
+    M m{name, nullptr, nullptr};
+    if (hipEventCreate(&m.a) != hipSuccess || hipEventCreate(&m.b) != hipSuccess) return (size_t)-1;
+    (void)hipEventRecord(m.a, s);
+    marks.push_back(m);
+    return marks.size() - 1;
+  }
+  void End(size_t i, hipStream_t s) { if (i < marks.size()) (void)hipEventRecord(marks[i].b, s); }
+  void Publish(std::vector<std::pair<const char*, float>>* out) {
+    out->clear();
+    for (auto& m : marks) {
+      float ms = 0.f;
+      if (hipEventSynchronize(m.b) == hipSuccess && hipEventElapsedTime(&ms, m.a, m.b) == hipSuccess) out->push_back({m.name, ms});
+    }
+  }
+};
+thread_local std::vector<std::pair<const char*, float>> g_last_save_stages;
+
 void Progress(ProgressProc progress, int percent) {
   if (progress && !progress(percent)) throw EncFail(EncoderStatus_UserCanceled, "");   // Encoder/JxlEncoder.cpp:79-89
 }
@@ -371,7 +395,8 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   if (im.has_alpha) im.alpha_px = A.Get<int32_t>(npx);
   Progress(progress, 15);
   clk.Lap("allocation");
-  LaunchEncFrontEnd(im, s);
+  StageMarks marks;
+  { const size_t k = marks.Begin("front_end (xyb, sharpen, activity, strategy, DCT + quantise)", s); LaunchEncFrontEnd(im, s); marks.End(k, s); }
   clk.Lap("xyb + sharpen + dct/quant");
   Progress(progress, 20);
   // ---- 4. tokens + histograms
@@ -383,7 +408,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.n_meta = A.Get<uint32_t>(im.nlf, true);
   im.hist_mod = A.Get<uint32_t>(kNumEncLeaves * kEncSyms, true);
   im.hist_ac = A.Get<uint32_t>((size_t)kAcContexts * kEncSyms, true);
-  LaunchEncTokens(im, s);
+  { const size_t k = marks.Begin("tokens + histograms", s); LaunchEncTokens(im, s); marks.End(k, s); }
   std::vector<uint32_t> hist_mod(kNumEncLeaves * kEncSyms), hist_ac((size_t)kAcContexts * kEncSyms);
   ENC_HIP(hipMemcpy(hist_mod.data(), im.hist_mod, hist_mod.size() * 4, hipMemcpyDeviceToHost));
   ENC_HIP(hipMemcpy(hist_ac.data(), im.hist_ac, hist_ac.size() * 4, hipMemcpyDeviceToHost));
@@ -421,7 +446,7 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   im.sec_bits = A.Get<uint64_t>(nsec, true);
   im.stream_state = A.Get<uint32_t>((size_t)2 * (im.nlf + im.ng) + 1, true);
   ENC_HIP(hipDeviceSynchronize());   // tokens, histogram downloads and the clears above are done before the other stream starts
-  LaunchEncReverse(im, 0, s_ans);
+  { const size_t k = marks.Begin("ans recurrences, Modular streams (LF, metadata, alpha)", s_ans); LaunchEncReverse(im, 0, s_ans); marks.End(k, s_ans); }
   if (im.has_alpha) lf_global.Write(4, 3);   // global Modular image header: global tree, default predictor, no transforms
   hf_global.Bool(true);                      // default dequantisation matrices
   hf_global.Write(im.ng <= 1 ? 0 : 32 - __builtin_clz((unsigned)(im.ng - 1)), 0);   // one HF preset
@@ -434,13 +459,15 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   clk.Lap("host: HF code (overlaps the LF recurrences)");
   // ---- 6. ANS coding of every section on the GPU (the Modular streams' recurrences have been running since their code was built)
   im.acode = UploadCode(A, acode);
-  LaunchEncReverse(im, 1, s_hf);
+  { const size_t k = marks.Begin("ans recurrences, HF streams", s_hf); LaunchEncReverse(im, 1, s_hf); marks.End(k, s_hf); }
   {
     hipEvent_t hf_done;
     ENC_HIP(hipEventCreateWithFlags(&hf_done, hipEventDisableTiming));
     ENC_HIP(hipEventRecord(hf_done, s_hf));
     ENC_HIP(hipStreamWaitEvent(s_ans, hf_done, 0));
+    const size_t k = marks.Begin("section bit layout", s_ans);
     LaunchEncSections(im, s_ans);   // bit layout of every section: needs the states of both kinds of stream
+    marks.End(k, s_ans);
     ENC_HIP(hipStreamSynchronize(s_ans));
     (void)hipEventDestroy(hf_done);
   }
@@ -453,10 +480,13 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
   {
     uint64_t* d_off = A.Upload(off);
     uint8_t* d_packed = A.Get<uint8_t>(packed.size());
+    const size_t k = marks.Begin("compact", s);
     LaunchEncCompact(im, d_off, d_packed, nsec, s);
+    marks.End(k, s);
     ENC_HIP(hipMemcpy(packed.data(), d_packed, packed.size(), hipMemcpyDeviceToHost));
   }
   ENC_HIP(hipGetLastError());
+  marks.Publish(&g_last_save_stages);
   clk.Lap("compact + download");
   Progress(progress, 30);
   // ---- 7. codestream assembly
@@ -496,6 +526,18 @@ void EncodeLossy(const BitmapData* bmp, const EncoderOptions* opt, const Encoder
 }  // namespace jxlhip
 
 using namespace jxlhip;
+
+// Device time of the kernel groups of this thread's last lossy SaveImage (see StageMarks)
+extern "C" JXLFILETYPEIO_API int32_t jxlhip_last_save_stage_times(const char** names, float* ms, int32_t capacity) {
+  int32_t k = 0;
+  for (auto& e : g_last_save_stages) {
+    if (k >= capacity) break;
+    if (names) names[k] = e.first;
+    if (ms) ms[k] = e.second;
+    k++;
+  }
+  return k;
+}
 
 extern "C" JXLFILETYPEIO_API EncoderStatus SaveImage(const BitmapData* bitmap, const EncoderOptions* options, const EncoderImageMetadata* metadata,
                                    IOCallbacks* callbacks, ErrorInfo* err, ProgressProc progress) {

@@ -736,11 +736,22 @@ __device__ __forceinline__ void RowScalar(LaneBits& b, uint32_t& state, TabPtr d
   first_out = s_first;
 }
 
+#include "modular_uniform.h"
+
+// LDS areas of the one-section-per-wavefront per-sample decoder (modular_uniform.h); unused (null) in every other launch shape
+struct UniAreas {
+  JXL_LDS int32_t* rows = nullptr;   // 3 * rw
+  JXL_LDS int32_t* wp = nullptr;     // 10 * (rw + 2), null when the tree does not use the weighted predictor
+  JXL_LDS uint32_t* grid = nullptr;  // kUniGridCells records of 16 bytes
+  int rw = 0;
+  bool use_wp = false;
+};
+
 // Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
-template <bool kLds>
+template <bool kLds, bool kUni = false>
 __device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
                                   int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr,
-                                  const RowBuf<kLds>* lane_rows = nullptr) {
+                                  const RowBuf<kLds>* lane_rows = nullptr, const UniAreas* uni = nullptr) {
   ChanDesc d;
   d.kind = kChanFinal; d.value = 0; d.pad0 = 0; d.pad1 = 0;
   if (w <= 0 || h <= 0) { *desc = d; return; }
@@ -751,6 +762,15 @@ __device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, 
   const int cls = (wp_scratch || tab.slow) ? 0 : ClassifyChannel<kLds>(tab, tree, chan, sid, w, h, &needs_n, &cval);
   if (cls == 2) { d.kind = kChanConst; d.value = cval; *desc = d; return; }
   if (cls == 0) {
+    if constexpr (kLds && kUni) {
+      // one section per wavefront, every lane alive: the per-sample chain on the scalar unit, the lanes as its neighbour / threshold /
+      // division tables (modular_uniform.h); channels it does not take (wide rows, general symbol reader) fall through
+      if (uni && uni->rows && ModularChannelUniform(b, state, tab, tree, chan, sid, w, h, out_generic, stride, uni->rows, uni->rw, uni->use_wp ? uni->wp : nullptr,
+                                                    uni->grid, kUniGridCells, uni->use_wp)) {
+        *desc = d;
+        return;
+      }
+    }
     RowBuf<kLds> rbuf;
     rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
     if (lane_rows) rbuf = *lane_rows;   // previous row in LDS instead of re-reading the plane (store -> load round trips)
@@ -1784,25 +1804,37 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 
 // Phase A: one lane per section.  A frame with a single TOC entry is one bit stream: its lane walks global, LF group and pass
 // group one after the other.
-template <bool kLds>
+// kUni (launches with one section per wavefront, tables in LDS): all 64 lanes stay alive and compute the same (uniform) values - the
+// row-static loops already keep their chains on the scalar unit - so that per-sample channels can use the lanes (modular_uniform.h).
+// LDS of that shape: bit windows | 3 rows | weighted-predictor rows | grid | tree + code.
+template <bool kLds, bool kUni = false>
 __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
   // LDS: bit windows | previous-row buffers (rb_width ints per lane, interleaved) | weighted-predictor state | tree + code
   const size_t off_rows = (size_t)64 * kRingWords * 4;
-  const size_t off_wp = off_rows + (size_t)lanes * rb_width * 4;
+  const size_t off_wp = off_rows + (size_t)(kUni ? 3 : lanes) * rb_width * 4;
   const size_t wp_ints = (size_t)10 * (rb_width + 2);
-  const size_t off_tab = off_wp + (wp_lds ? (size_t)lanes * wp_ints * 4 : 0);
+  const size_t off_grid = off_wp + (wp_lds ? (size_t)lanes * wp_ints * 4 : 0);
+  const size_t off_tab = off_grid + (kUni ? (size_t)kUniGridCells * 16 : 0);
   ModTables<kLds> mt;
   LoadModTables<kLds>(im, smem, off_tab, mt, threadIdx.x, 64, lanes == 1 && scalar_rows);
-  const int lane = threadIdx.x;
+  const int lane = kUni ? 0 : (int)threadIdx.x;   // kUni: every lane plays lane 0 (same slot, same section)
   if (lane >= task.count || lane >= lanes) return;
   RowBuf<kLds> rows;
   rows.rb = (typename AS<kLds>::Row)((JXL_LDS int32_t*)((JXL_LDS uint8_t*)smem + off_rows) + lane);
   rows.rb_stride = lanes;
   rows.rb_width = rb_width;
   int32_t* const wp_local = wp_lds ? (int32_t*)(smem + off_wp) + (size_t)lane * wp_ints : nullptr;
+  UniAreas uni;
+  if constexpr (kUni) {
+    uni.rows = (JXL_LDS int32_t*)((JXL_LDS uint8_t*)smem + off_rows);
+    uni.wp = wp_lds ? (JXL_LDS int32_t*)((JXL_LDS uint8_t*)smem + off_wp) : nullptr;
+    uni.grid = (JXL_LDS uint32_t*)((JXL_LDS uint8_t*)smem + off_grid);
+    uni.rw = rb_width;
+    uni.use_wp = im.wp_grp != nullptr && wp_lds;
+  }
   const int s0 = task.first + lane;
   const int nsub = im.single ? 3 : 1;   // single: this lane continues through sections 0, 1, 2
   LaneBits b;
@@ -1842,8 +1874,8 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
       const ModChanDev ch = im.mod_chan[c];
       ModRect r;
       if (!ModSectionRect(im, kind, g, ch, c, &r)) continue;
-      DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, sub, sid, r.w, r.h, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, desc + c,
-                              (wps && wp_local && r.w <= rb_width) ? wp_local : wps, rb_width ? &rows : nullptr);
+      DecodeChannelLane<kLds, kUni>(b, state, mt.tab, mt.tree, sub, sid, r.w, r.h, ch.plane + (size_t)r.y0 * ch.w + r.x0, ch.w, desc + c,
+                                    (wps && wp_local && r.w <= rb_width) ? wp_local : wps, rb_width ? &rows : nullptr, kUni ? &uni : nullptr);
       sub++;
     }
     if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
@@ -2054,7 +2086,10 @@ void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int
 void LaunchModularAns(const DevImage* imgs, int nimg, const SectionTask* tasks, int ntasks, size_t lds_bytes, int max_sections, int max_coded,
                       int lanes, int rb_width, int wp_lds, int scalar_rows, hipStream_t s) {
   if (ntasks <= 0) return;
-  if (lds_bytes) {
+  if (lds_bytes && lanes == 1 && rb_width > 0) {   // one section per wavefront: the uniform shape (host sizes lds_bytes for its layout)
+    RaiseLds((const void*)modular_ans_kernel<true, true>, lds_bytes);
+    hipLaunchKernelGGL((modular_ans_kernel<true, true>), dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds, scalar_rows);
+  } else if (lds_bytes) {
     RaiseLds((const void*)modular_ans_kernel<true>, lds_bytes);
     hipLaunchKernelGGL(modular_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, lanes, rb_width, wp_lds, scalar_rows);
   } else {

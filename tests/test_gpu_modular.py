@@ -130,3 +130,35 @@ def test_palette_with_prefix_codes_and_lz77(oracle):
     img = _palette_image(520, 300, 12, 4, 3)
     data = oracle.encode(img, lossless=True, palette=True, prefix_codes=True, lz77=True)
     assert (api.load_image(data).pixels == img).all()
+
+
+@pytest.mark.parametrize("kind", ["u16", "u16-extremes", "f32", "f16"])
+@pytest.mark.parametrize("squeeze", [False, True], ids=["plain", "squeeze"])
+def test_weighted_predictor_with_deep_samples(oracle, kind, squeeze):
+    """The weighted predictor on deep samples: 16-bit integers stay inside the 32-bit form of the one-section-per-wavefront decoder
+    (csrc/modular_uniform.h), float bit patterns (up to 2^30) leave it - the channel then continues in the 64-bit form.  Both must
+    be bit-exact against the source and the oracle, also where the two forms meet inside one channel."""
+    from pdn_jpegxl_amd.synth import synth16
+    if kind == "u16":
+        src = np.ascontiguousarray(synth16(300, 270, 31)[..., :3])
+        data = oracle.encode(src, lossless=True, bits=16, lossless_squeeze=squeeze)
+    elif kind == "u16-extremes":
+        src = np.ascontiguousarray(synth16(200, 120, 32)[..., :3])
+        src[20:60, 30:90] = 65535          # hard edges between the extremes: the largest errors a 16-bit image can make
+        src[20:60, 90:150] = 0
+        src[70:100, ::2] = 65535
+        data = oracle.encode(src, lossless=True, bits=16, lossless_squeeze=squeeze)
+    else:
+        base = synth(200, 150, 33)[..., :3].astype(np.float32) / 255.0
+        if kind == "f32":
+            base[10:40, 10:60] *= 1e-3      # small magnitudes: bit patterns far below those of the values near one
+            src = base.astype(np.float32)
+            data = oracle.encode(src, lossless=True, float_samples=32, lossless_squeeze=squeeze)
+        else:
+            src = base.astype(np.float16)
+            data = oracle.encode(src, lossless=True, float_samples=16, lossless_squeeze=squeeze)
+    got = api.load_image(data)
+    ref = oracle.decode(data).pixels
+    assert got.pixels.dtype == src.dtype and got.pixels.shape == src.shape
+    assert np.array_equal(got.pixels.view(np.uint8), ref.view(np.uint8))
+    assert np.array_equal(got.pixels.view(np.uint8), np.ascontiguousarray(src).view(np.uint8))

@@ -102,13 +102,16 @@ struct UniCtx {
   bool cfg_in_lanes;
   // the grid
   bool grid_ok, leaf_in_lanes;
-  uint64_t slot_range[kUniMaxProps];   // lanes of slot k in the threshold register
-  uint32_t slot_stride[kUniMaxProps];
-  int64_t vthr;                         // threshold of this lane (+inf in unused lanes)
+  // the thresholds of property slot k sit in FIXED lanes - two slots of 32 lanes (layout32) or four of 16 - so that the bucket of a
+  // slot is a population count of a constant bit field of the compare mask (no per-slot masks to keep in registers)
+  bool layout32;
+  uint32_t stride1, stride2, stride3;   // grid strides of slots 1 .. 3 (slot 0: 1)
+  int64_t vthr;                         // threshold of this lane (unused lanes lie outside every slot's range)
+  int32_t vthr32;                       // the same as the 32-bit number the stream carries
   int32_t vcW, vcN, vcNW, vcNE, vcNN, vcWW, vcX, vcY, vcE;   // coefficients of this lane's property
   bool vabs, vp8;                       // ... its absolute-value flag; property 8 (subtracts the previous W + N - NW)
   bool use_far, use_xy, use_e, use_p8, use_abs;   // which input groups any lane needs
-  int32_t vleaf0, vleaf1, vleaf2;       // grids of at most 64 cells: the leaf record of cell `lane`
+  int32_t vleaf0, vleaf1, vleaf2;       // grids of at most 64 cells: the leaf record of cell `lane` (packed word, multiplier, offset)
   const JXL_LDS U4* grid;
   // stream state
   uint32_t s_state, s_rd;
@@ -128,7 +131,7 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
   auto word = [&]() {
     if (__builtin_expect(s_n <= 32, 0)) { s_buf |= (uint64_t)JXL_RFL(ring[__umul24(s_rd & (kRingWords - 1), ring_rs)]) << s_n; s_n += 32; s_rd++; }
   };
-  bool big = false;   // (weighted predictor) a sample or an error beyond the 32-bit form's bound has been seen
+  bool big = false;   // a sample (or an error of the weighted predictor) beyond the bound of the 32-bit forms has been seen
   for (int y = 0; y < h; y++) {
     JXL_LDS int32_t* const cur = c.rows + (y % 3) * rw;
     JXL_LDS int32_t* const prv = c.rows + ((y + 2) % 3) * rw;
@@ -160,17 +163,17 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
         vTene = xl + 1 < w ? c.werr[prev_o + xl + 1] : 0;
       }
       int32_t vout = 0, vEo[4] = {0, 0, 0, 0}, vTo = 0;
+      if (x0 == 0) {   // start of the row: West, North and North-West are the sample above (0 in the top row)
+        W = y ? UReadLane(vN0, 0) : 0;
+        N = W; NW = W; WW = W;
+        prev9 = 0;
+      }
       for (int p0 = 0; p0 < cnt; p0 += kTopUpEvery) {
         b.rd = s_rd;
         b.TopUp();
         const int pe = min(cnt, p0 + kTopUpEvery);
         for (int li = p0; li < pe; li++) {
           const int x = x0 + li;
-          if (x == 0) {
-            W = y ? UReadLane(vN0, 0) : 0;
-            N = W; NW = W; WW = W;
-            prev9 = 0;
-          }
           const int32_t NE = (y && x + 1 < w) ? UReadLane(vNE, (uint32_t)li) : N;
           const int32_t NN = y > 1 ? UReadLane(vNN, (uint32_t)li) : N;
           // ---- weighted predictor (the format's arithmetic).  While every sample and error seen so far is small (`big` unset:
@@ -265,27 +268,41 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
             teN_prev = teN;
           }
           // ---- leaf
-          uint32_t l_pred, l_cl, l_mul;
+          uint32_t l_pred, l_cl, l_mul, l_cfg;
           int32_t l_off;
           if (c.grid_ok) {
-            // every threshold lane evaluates its property: a signed sum over the neighbourhood, coefficients per lane
-            int64_t pv = (int64_t)c.vcW * W + (int64_t)c.vcN * N + (int64_t)c.vcNW * NW;
-            if (c.use_far) pv += (int64_t)c.vcNE * NE + (int64_t)c.vcNN * NN + (int64_t)c.vcWW * WW;
-            if (c.use_xy) pv += (int64_t)c.vcX * x + (int64_t)c.vcY * y;
-            if (c.use_e) pv += (int64_t)c.vcE * wp_err;
-            if (c.use_p8) pv -= c.vp8 ? prev9 : 0;
-            if (c.use_abs) pv = (c.vabs && pv < 0) ? -pv : pv;
-            const uint64_t gt = __ballot(pv > c.vthr);
-            uint32_t cell = 0;
-#pragma unroll
-            for (int k = 0; k < kUniMaxProps; k++) cell += (uint32_t)__popcll(gt & c.slot_range[k]) * c.slot_stride[k];
-            if (c.leaf_in_lanes) {
-              const uint32_t r0 = (uint32_t)UReadLane(c.vleaf0, cell);
-              l_pred = r0 & 0xFF; l_cl = r0 >> 8; l_mul = (uint32_t)UReadLane(c.vleaf1, cell); l_off = UReadLane(c.vleaf2, cell);
+            // every threshold lane evaluates its property: a signed sum over the neighbourhood, coefficients per lane.  While the
+            // samples are small (`big` unset) the sum fits 32 bits with room to spare and is a handful of full-rate multiply-adds
+            // with no branch at all; thresholds are 32-bit numbers in the stream, so the compare is a 32-bit one too
+            uint64_t gt;
+            if (__builtin_expect(!big, 1)) {
+              int32_t pv = c.vcW * W + c.vcN * N + c.vcNW * NW + c.vcNE * NE + c.vcNN * NN + c.vcWW * WW + c.vcX * x + c.vcY * y + c.vcE * wp_err -
+                           (c.vp8 ? (int32_t)prev9 : 0);
+              pv = c.vabs ? abs(pv) : pv;
+              gt = __ballot(pv > c.vthr32);
             } else {
-              const U4 rec = c.grid[cell];
-              const uint32_t r0 = JXL_RFL(rec.x);
-              l_pred = r0 & 0xFF; l_cl = r0 >> 8; l_mul = JXL_RFL(rec.y); l_off = (int32_t)JXL_RFL(rec.z);
+              int64_t pv = (int64_t)c.vcW * W + (int64_t)c.vcN * N + (int64_t)c.vcNW * NW;
+              if (c.use_far) pv += (int64_t)c.vcNE * NE + (int64_t)c.vcNN * NN + (int64_t)c.vcWW * WW;
+              if (c.use_xy) pv += (int64_t)c.vcX * x + (int64_t)c.vcY * y;
+              if (c.use_e) pv += (int64_t)c.vcE * wp_err;
+              if (c.use_p8) pv -= c.vp8 ? prev9 : 0;
+              if (c.use_abs) pv = (c.vabs && pv < 0) ? -pv : pv;
+              gt = __ballot(pv > c.vthr);
+            }
+            uint32_t cell;
+            const uint32_t glo = (uint32_t)gt, ghi = (uint32_t)(gt >> 32);
+            if (c.layout32) cell = (uint32_t)__builtin_popcount(glo) + (uint32_t)__builtin_popcount(ghi) * c.stride1;
+            else cell = (uint32_t)__builtin_popcount(glo & 0xFFFFu) + (uint32_t)__builtin_popcount(glo >> 16) * c.stride1 +
+                        (uint32_t)__builtin_popcount(ghi & 0xFFFFu) * c.stride2 + (uint32_t)__builtin_popcount(ghi >> 16) * c.stride3;
+            // the leaf as one packed word: predictor | cluster << 4 | hybrid-integer configuration << 12 | (multiplier 1, offset 0) << 24
+            uint32_t r0;
+            if (c.leaf_in_lanes) r0 = (uint32_t)UReadLane(c.vleaf0, cell);
+            else r0 = JXL_RFL(c.grid[cell].x);
+            l_pred = r0 & 0xF; l_cl = (r0 >> 4) & 0xFF; l_cfg = (r0 >> 12) & 0xFFF;
+            l_mul = 1; l_off = 0;
+            if (__builtin_expect(!(r0 >> 24), 0)) {
+              if (c.leaf_in_lanes) { l_mul = (uint32_t)UReadLane(c.vleaf1, cell); l_off = UReadLane(c.vleaf2, cell); }
+              else { const U4 rec = c.grid[cell]; l_mul = JXL_RFL(rec.y); l_off = (int32_t)JXL_RFL(rec.z); }
             }
           } else {
             UniHood hd;
@@ -298,6 +315,7 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
               nd = UniNode(c.tree, node);
             }
             l_pred = nd.a & 0xFF; l_cl = JXL_RFL(c.cmap[nd.a >> 8]); l_mul = nd.b; l_off = nd.splitval;
+            l_cfg = (c.cfg_in_lanes ? (uint32_t)UReadLane(c.vcfg, l_cl) : JXL_RFL(c.cfg[l_cl])) & 0xFFF;
           }
           // ---- predictor (kPred >= 0: every leaf of the channel uses it)
           const uint32_t pred = kPred >= 0 ? (uint32_t)kPred : l_pred;
@@ -337,7 +355,7 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
           const uint32_t res = s_state & 0xFFF, ai = res >> c.le, pos = res & ((1u << c.le) - 1);
           const uint64_t ae = c.alias[(l_cl << c.la) | ai];
           const uint32_t ax = JXL_RFL((uint32_t)ae), ay = JXL_RFL((uint32_t)(ae >> 32));
-          const uint32_t cf = c.cfg_in_lanes ? (uint32_t)UReadLane(c.vcfg, l_cl) : JXL_RFL(c.cfg[l_cl]);
+          const uint32_t cf = l_cfg;
           const bool gtc = pos >= (ax & 0xFF);
           const uint32_t sym = gtc ? ((ax >> 8) & 0xFF) : ai;
           const uint32_t aoff = gtc ? (ay & 0xFFFF) + pos : pos;
@@ -363,10 +381,11 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
           }
           const int32_t val = (int32_t)((int64_t)UnpackSigned(u) * (int64_t)l_mul + l_off + guess);
           vout = UWriteLane(val, (uint32_t)li, vout);
+          big = big || (uint32_t)(val + (1 << 18)) >= (1u << 19);   // the bound of the 32-bit forms (properties, weighted predictor)
           if constexpr (kWp) {
             int32_t terr;
-            // (the sample just decoded is the one value not yet checked: its own update already takes the 64-bit form when it is large)
-            big = big || (uint32_t)(val + (1 << 18)) >= (1u << 19);
+            // (the sample just decoded is the one value not yet checked - `big` was raised for it above: its own update already
+            // takes the 64-bit form when it is large)
             if (__builtin_expect(!big, 1)) {
               const int32_t v8 = val << 3;
               terr = (int32_t)wpred8 - v8;
@@ -515,16 +534,19 @@ __device__ __forceinline__ bool ModularChannelUniform(LaneBits& b, uint32_t& sta
   }
   int strd[kUniMaxProps] = {0, 0, 0, 0}, lane0[kUniMaxProps] = {0, 0, 0, 0};
   uint32_t cells = 1;
-  int total_thr = 0;
+  int max_thr = 0;
+#pragma unroll
+  for (int k = 0; k < kUniMaxProps; k++) max_thr = max(max_thr, nthr[k]);
+  const bool layout32 = nprops <= 2;
+  if (max_thr > (layout32 ? 32 : 16)) grid_ok = false;
   if (grid_ok) {
 #pragma unroll
     for (int k = 0; k < kUniMaxProps; k++)
       if (k < nprops) {
         strd[k] = (int)cells;
-        lane0[k] = total_thr;
-        total_thr += nthr[k];
+        lane0[k] = layout32 ? 32 * k : 16 * k;
         cells *= (uint32_t)(nthr[k] + 1);
-        if (cells > (uint32_t)grid_cells || total_thr > 64) grid_ok = false;
+        if (cells > (uint32_t)grid_cells) grid_ok = false;
       }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -532,7 +554,7 @@ __device__ __forceinline__ bool ModularChannelUniform(LaneBits& b, uint32_t& sta
   int all_pred = -1;
   if (grid_ok) {
     // every cell: representative values of its buckets (bucket q of sorted thresholds t: values > t[q-1] and <= t[q]), one walk
-    bool mixed = false;
+    bool mixed = false, unknown_pred = false;
     uint32_t first_pred = 0;
     for (uint32_t c0 = 0; c0 < cells; c0 += 64) {
       const uint32_t cell = c0 + (uint32_t)lane;
@@ -560,7 +582,10 @@ __device__ __forceinline__ bool ModularChannelUniform(LaneBits& b, uint32_t& sta
       if (__ballot(cell < cells && (a & 0xFF) != first_pred)) mixed = true;
       if (cell < cells) {
         U4 rec;
-        rec.x = (a & 0xFF) | (uint32_t)c.cmap[a >> 8] << 8;
+        const uint32_t cl = c.cmap[a >> 8];
+        const bool plain = (uint32_t)v.w == 1u && v.y == 0;
+        if ((a & 0xFF) > 13) unknown_pred = true;
+        rec.x = (a & 0xF) | cl << 4 | (c.cfg[cl] & 0xFFFu) << 12 | (plain ? 1u << 24 : 0u);
         rec.y = (uint32_t)v.w;      // multiplier
         rec.z = (uint32_t)v.y;      // offset
         rec.w = a >> 8;             // context (diagnostics)
@@ -568,22 +593,23 @@ __device__ __forceinline__ bool ModularChannelUniform(LaneBits& b, uint32_t& sta
       }
     }
     if (!mixed) all_pred = (int)first_pred;
+    if (__ballot(unknown_pred)) grid_ok = false;   // a predictor id the format does not have: the tree walk's default case deals with it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
   // ---- per-lane tables of the grid: thresholds of all slots in one register, the coefficients of each lane's property
   c.grid_ok = grid_ok;
   c.leaf_in_lanes = grid_ok && cells <= 64;
-  c.vthr = INT64_MAX;
+  c.layout32 = layout32;
+  c.stride1 = (uint32_t)strd[1]; c.stride2 = (uint32_t)strd[2]; c.stride3 = (uint32_t)strd[3];
+  c.vthr = INT64_MAX;       // unused lanes: no value is greater, they never count
+  c.vthr32 = INT32_MAX;
   int vpid = 0;
 #pragma unroll
   for (int k = 0; k < kUniMaxProps; k++) {
-    c.slot_range[k] = 0; c.slot_stride[k] = 0;
     if (grid_ok && k < nprops) {
       const int64_t t = __shfl(thr[k], (lane - lane0[k]) & 63);
-      if (lane >= lane0[k] && lane < lane0[k] + nthr[k]) { c.vthr = t; vpid = prop_id[k]; }
-      c.slot_range[k] = nthr[k] ? ((nthr[k] >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << nthr[k]) - 1)) << lane0[k]) : 0;
-      c.slot_stride[k] = (uint32_t)strd[k];
+      if (lane >= lane0[k] && lane < lane0[k] + nthr[k]) { c.vthr = t; c.vthr32 = (int32_t)t; vpid = prop_id[k]; }
     }
   }
   c.vcW = (vpid == 5 || vpid == 7 || vpid == 8 || vpid == 9 || vpid == 10 || vpid == 14) ? 1 : 0;

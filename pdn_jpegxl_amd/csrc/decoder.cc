@@ -713,7 +713,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
-  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false;
+  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false, any_fused2 = false;
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
@@ -987,8 +987,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     for (int s = 0; s < 4; s++) if (d.stage_on[s]) d.final_stage = s;
     if (debug_taps) d.final_stage = 4;   // keep the filtered float planes for the stage taps; out_only_kernel converts
     // the common configuration (Gaborish + one EPF iteration) runs as ONE kernel: the Gaborish result never leaves LDS
-    d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : 0;
-    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = 0; d.final_stage = 5; any_fused = true; }
+    // ... and two iterations as two streaming kernels (the first one's rows go through the f32 planes of stage_out[0])
+    d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : ((!debug_taps && f.gab && f.epf_iters == 2) ? 2 : 0);
+    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5; any_fused = true; any_fused2 |= d.fused_gab_epf1 == 2; }
     any_unfiltered |= d.final_stage == 4;
     max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
     max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));
@@ -1156,7 +1157,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     Mark("reconstruct_generic", s_pix, 2);
     if (debug_taps) { HIP_OK(hipStreamSynchronize(s_pix)); CopyPlaneTap(1); }
     if (!(skip_stages & 16))
-    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, s_pix);
+    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, any_fused2, s_pix);
     Mark("filters+output", s_pix, 2);
   }
   if (s_pix != stream) {

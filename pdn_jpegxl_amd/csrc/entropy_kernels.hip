@@ -904,6 +904,41 @@ __device__ __forceinline__ void TileSync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
+// The step loop of PredictWaveTiled for a band whose rows all use the clamped gradient (what alpha and LF channels are written with):
+// the same recurrence without the per-row predictor select, with every lane reading its next residual / the carried row at a clamped
+// index instead of under an exec mask, and the carried row copied out of the tile afterwards instead of by one lane per step.
+// kFirstTile: the tile starts at column 0 (a row's first sample has no West / North-West); kTopBand: lane 0 is the channel's top row.
+template <bool kFirstTile, bool kTopBand>
+__device__ __forceinline__ void GradientTileSteps(JXL_LDS int32_t* trow, const JXL_LDS int32_t* carry_x0, int ncols, int nrows, int lane, bool row_active,
+                                                  int32_t& W, int32_t& N, int32_t& NW, int32_t& val) {
+  const int steps = ncols + nrows - 1;
+  const bool top = kTopBand && lane == 0;
+  int32_t r_next = trow[0], up0_next = kTopBand ? 0 : carry_x0[0];
+  for (int t = 0; t < steps; t++) {
+    const int32_t from_up = FromLaneBelow(val);   // lane r-1's value of the previous step = sample (x, y-1)
+    const int c = t - lane;
+    const int32_t r = r_next, up0 = up0_next;
+    const int cn = min(max(c + 1, 0), ncols - 1);
+    r_next = trow[cn];
+    if (!kTopBand) up0_next = carry_x0[cn];
+    if (row_active && (unsigned)c < (unsigned)ncols) {
+      const int32_t n_in = lane == 0 ? up0 : from_up;
+      int32_t n = n_in;
+      if (kTopBand) n = top ? W : n_in;            // top row: North = North-West = West
+      int32_t nw = kTopBand ? (top ? W : N) : N;
+      if (kFirstTile && c == 0) {                  // first column: West = North = North-West = the sample above (0 in the top row)
+        const int32_t w0 = top ? 0 : n_in;
+        W = w0; n = w0; nw = w0;
+      }
+      val = (int32_t)((uint32_t)r + (uint32_t)ClampedGradient32(W, n, nw));
+      trow[c] = val;
+      W = val;
+      N = n;
+    }
+  }
+  NW = N;
+}
+
 template <bool kU8Out>
 __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* plane_generic, int stride, int w, int h, int kind, int32_t cvalue,
                                  uint8_t* out8_generic, int out_stride, JXL_LDS int32_t* carry, JXL_LDS int32_t* tile, int lane) {
@@ -934,6 +969,18 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
       // The residual of the step after this one and (lane 0) the sample above it are requested a step early: LDS latency
       // then overlaps the arithmetic instead of adding to the recurrence.
       JXL_LDS int32_t* const trow = tile + lane * kTilePitch;
+      const bool grad_band = kind == kChanResid && __ballot(row_active && pred != 5) == 0;   // (uniform)
+      if (grad_band) {
+        if (x0 == 0) {
+          if (y0 == 0) GradientTileSteps<true, true>(trow, carry + x0, ncols, nrows, lane, row_active, W, N, NW, val);
+          else GradientTileSteps<true, false>(trow, carry + x0, ncols, nrows, lane, row_active, W, N, NW, val);
+        } else {
+          if (y0 == 0) GradientTileSteps<false, true>(trow, carry + x0, ncols, nrows, lane, row_active, W, N, NW, val);
+          else GradientTileSteps<false, false>(trow, carry + x0, ncols, nrows, lane, row_active, W, N, NW, val);
+        }
+        TileSync();
+        if (more && lane < ncols) carry[x0 + lane] = tile[(nrows - 1) * kTilePitch + lane];   // the band's last row, for the band below
+      } else {
       const bool top = y == 0, keeps_carry = more && lane == nrows - 1;
       int32_t r_next = cvalue, up0_next = 0;
       if (lane == 0 && row_active) {
@@ -961,6 +1008,7 @@ __device__ void PredictWaveTiled(const I4* tree, int chan, int sid, int32_t* pla
           if (keeps_carry) carry[x0 + c] = val;
           W = val;
         }
+      }
       }
       TileSync();
       if (kU8Out && ncols == 64 && ((out_stride | x0) & 3) == 0 && ((uintptr_t)out8_generic & 3) == 0) {

@@ -648,6 +648,8 @@ struct StreamConst {
   float gw0[3], gw1[3], gw2[3], cs[3], bsm;
   int X, w, h, wp, w8, y0, y1, r_end, cellx, xa;
   bool interior, stores, full_quad, plain, xb0, xb3;
+  JXL_GLOBAL float *f0, *f1, *f2;   // two EPF iterations: the first one's rows leave as f32 planes (filter_stream2_kernel reads them)
+  bool to_float;
 };
 
 // One input row r (phase P = (r - first row) & 3): Gaborish row r - 1, differences, and the output row r - 3.
@@ -707,7 +709,11 @@ __device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst&
       const F4 f = (g1 + wu * st.g[s0].c[c] + wl * ShiftFromLeft(g1) + wr * ShiftFromRight(g1) + wd * st.g[s2].c[c]) * iw;
       o[c] = skip ? g1 : f;
     }
-    if (k.stores) {
+    if (k.stores && k.to_float) {
+      // (the planes are padded to whole 8x8 cells: a quad that starts inside the frame ends inside the plane)
+      const size_t g = (size_t)y * k.wp + k.X;
+      *(JXL_GLOBAL F4*)(k.f0 + g) = o[0]; *(JXL_GLOBAL F4*)(k.f1 + g) = o[1]; *(JXL_GLOBAL F4*)(k.f2 + g) = o[2];
+    } else if (k.stores) {
       if (k.plain && im.nch_out == 4 && k.full_quad) {
         typedef unsigned __attribute__((ext_vector_type(4))) U4v;
         U4v px;
@@ -740,7 +746,10 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
   StreamConst k;
   k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8;
   const int strips = (k.w + kStripOut - 1) / kStripOut;
-  const int band_rows = im.band_y1 - im.band_y0;
+  // two EPF iterations: this kernel's rows feed the second iteration, which looks one row up and down
+  k.to_float = im.fused_gab_epf1 == 2;
+  const int band_lo = k.to_float ? max(0, im.band_y0 - 1) : im.band_y0, band_hi = k.to_float ? min(k.h, im.band_y1 + 1) : im.band_y1;
+  const int band_rows = band_hi - band_lo;
   const int segs = (band_rows + kSegRows - 1) / kSegRows;
   if ((int)blockIdx.x * 16 >= strips * segs) return;   // whole workgroup past the end
   // every lane stays in the loop (DPP reads neighbouring lanes); groups past the end repeat the last task and store nothing
@@ -750,7 +759,7 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
   const int strip = gi % strips, seg = gi / strips;
   const int q = threadIdx.x & 15;
   k.X = strip * kStripOut - 4 + 4 * q;           // first column of this lane's quad
-  k.y0 = im.band_y0 + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, im.band_y1);
+  k.y0 = band_lo + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, band_hi);
   k.r_end = k.y1 + 3;
   k.interior = k.X >= 0 && k.X + 3 < k.w;
   k.stores = task && q >= 1 && q <= 14 && k.X < k.w;
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
   k.inv_sigma = (const JXL_GLOBAL float*)im.inv_sigma;
   k.alpha = (const JXL_GLOBAL uint8_t*)im.alpha;
   k.plain = PlainOutput(im);
+  k.f0 = (JXL_GLOBAL float*)im.stage_out[0][0]; k.f1 = (JXL_GLOBAL float*)im.stage_out[0][1]; k.f2 = (JXL_GLOBAL float*)im.stage_out[0][2];
 #pragma unroll
   for (int c = 0; c < 3; c++) { k.gw0[c] = im.gab_w[c][0]; k.gw1[c] = im.gab_w[c][1]; k.gw2[c] = im.gab_w[c][2]; k.cs[c] = im.epf_channel_scale[c]; }
   k.bsm = im.epf_border_sad_mul;
@@ -788,6 +798,102 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
   }
 }
 
+// The second EPF iteration (frames with two: distance 1.5 ... 4) + XYB -> output samples, register streaming like the kernel above
+// but much lighter: three rows of the first iteration's output (f32 planes), four neighbours, a one-pixel SAD.  Same strip geometry
+// (a DPP row of 16 lanes = 64 columns, the outer quads are halo), same output paths.  With it a two-iteration frame runs
+// reconstruction -> two streaming kernels instead of three LDS-tiled stage kernels (measured, 384 4K frames at distance 2:
+// filters + output 104.8 ms before).
+__global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  if (im.fused_gab_epf1 != 2) return;
+  const int w = im.w, h = im.h, wp = im.wp;
+  const int strips = (w + kStripOut - 1) / kStripOut;
+  const int band_rows = im.band_y1 - im.band_y0;
+  const int segs = (band_rows + kSegRows - 1) / kSegRows;
+  if ((int)blockIdx.x * 16 >= strips * segs) return;
+  const int gidx = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool task = gidx < strips * segs;
+  const int gi = task ? gidx : strips * segs - 1;
+  const int strip = gi % strips, seg = gi / strips;
+  const int q = threadIdx.x & 15;
+  const int X = strip * kStripOut - 4 + 4 * q;
+  const int y0 = im.band_y0 + seg * kSegRows, y1 = min(y0 + kSegRows, im.band_y1);
+  const bool interior = X >= 0 && X + 3 < w;
+  const bool stores = task && q >= 1 && q <= 14 && X < w;
+  const bool full_quad = X + 3 < w;
+  const JXL_GLOBAL float* in0 = (const JXL_GLOBAL float*)im.stage_out[0][0];
+  const JXL_GLOBAL float* in1 = (const JXL_GLOBAL float*)im.stage_out[0][1];
+  const JXL_GLOBAL float* in2 = (const JXL_GLOBAL float*)im.stage_out[0][2];
+  const JXL_GLOBAL float* inv_sigma = (const JXL_GLOBAL float*)im.inv_sigma;
+  const bool plain = PlainOutput(im);
+  const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
+  const float sm = im.epf_pass2_sigma_scale, smb = sm * im.epf_border_sad_mul;
+  const bool xb0 = (q & 1) != 0, xb3 = (q & 1) == 0;
+  const int cellx = min(max(X, 0), w - 1) >> 3;
+  const int xa = min(max(X, 0), max(w - 4, 0));
+  Row3 prev = LoadRow3(in0, in1, in2, X, y0 - 1, w, h, wp, interior);
+  Row3 cur = LoadRow3(in0, in1, in2, X, y0, w, h, wp, interior);
+  for (int y = y0; y < y1; y++) {
+    const Row3 next = LoadRow3(in0, in1, in2, X, y + 1, w, h, wp, interior);
+    const float is = inv_sigma[(size_t)(y >> 3) * im.w8 + cellx];
+    uint32_t al = 0xFFFFFFFFu;
+    if (im.has_alpha && plain) {
+      const JXL_GLOBAL uint8_t* ap = (const JXL_GLOBAL uint8_t*)im.alpha + (size_t)y * w + xa;
+      al = (uint32_t)ap[0] | (uint32_t)ap[1] << 8 | (uint32_t)ap[2] << 16 | (uint32_t)ap[3] << 24;
+    }
+    const F4 zero = {0.f, 0.f, 0.f, 0.f};
+    F4 su = zero, sd = zero, sl = zero, sr = zero;
+    F4 lft[3], rgt[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float sc = c == 0 ? cs0 : (c == 1 ? cs1 : cs2);
+      lft[c] = ShiftFromLeft(cur.c[c]); rgt[c] = ShiftFromRight(cur.c[c]);
+      su += Abs4(cur.c[c] - prev.c[c]) * sc; sd += Abs4(cur.c[c] - next.c[c]) * sc;
+      sl += Abs4(cur.c[c] - lft[c]) * sc; sr += Abs4(cur.c[c] - rgt[c]) * sc;
+    }
+    const bool yb = ((y & 7) == 0) || ((y & 7) == 7);
+    const float inv_in = is * (yb ? smb : sm), inv_b = is * smb;
+    const F4 inv = {xb0 ? inv_b : inv_in, inv_in, inv_in, xb3 ? inv_b : inv_in};
+    const bool skip = is < -3.90524291751269967465540850526868f;
+    F4 wu, wl, wr, wd, iw;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      wu[j] = fmaxf(0.f, 1.0f + su[j] * inv[j]); wl[j] = fmaxf(0.f, 1.0f + sl[j] * inv[j]);
+      wr[j] = fmaxf(0.f, 1.0f + sr[j] * inv[j]); wd[j] = fmaxf(0.f, 1.0f + sd[j] * inv[j]);
+      iw[j] = __builtin_amdgcn_rcpf(1.0f + wu[j] + wl[j] + wr[j] + wd[j]);
+    }
+    F4 o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const F4 f = (cur.c[c] + wu * prev.c[c] + wl * lft[c] + wr * rgt[c] + wd * next.c[c]) * iw;
+      o[c] = skip ? cur.c[c] : f;
+    }
+    if (stores) {
+      if (plain && im.nch_out == 4 && full_quad) {
+        typedef unsigned __attribute__((ext_vector_type(4))) U4v;
+        U4v px;
+        px.x = PixelToRgba8(im, o[0].x, o[1].x, o[2].x, al & 0xFF);
+        px.y = PixelToRgba8(im, o[0].y, o[1].y, o[2].y, (al >> 8) & 0xFF);
+        px.z = PixelToRgba8(im, o[0].z, o[1].z, o[2].z, (al >> 16) & 0xFF);
+        px.w = PixelToRgba8(im, o[0].w, o[1].w, o[2].w, al >> 24);
+        *(JXL_GLOBAL U4v*)((JXL_GLOBAL uint8_t*)im.out + ((size_t)(y - im.band_y0) * w + X) * 4) = px;
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < 4; j++) {
+          if (X + j >= w) break;
+          const uint32_t aj = !im.has_alpha ? 0u : LoadAlpha(im, (size_t)y * w + X + j);
+          const float ox = j == 0 ? o[0].x : (j == 1 ? o[0].y : (j == 2 ? o[0].z : o[0].w));
+          const float oy = j == 0 ? o[1].x : (j == 1 ? o[1].y : (j == 2 ? o[1].z : o[1].w));
+          const float ob = j == 0 ? o[2].x : (j == 1 ? o[2].y : (j == 2 ? o[2].z : o[2].w));
+          WritePixelGeneral(im, X + j, y, ox, oy, ob, aj);
+        }
+      }
+    }
+    prev = cur;
+    cur = next;
+  }
+}
+
 // no loop filter at all: plain conversion
 __global__ void out_only_kernel(const DevImage* imgs) {
   const DevImage& im = imgs[blockIdx.y];
@@ -811,12 +917,14 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
-                       bool any_fused, hipStream_t s) {
+                       bool any_fused, bool any_fused2, hipStream_t s) {
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
-    const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + kSegRows - 1) / kSegRows);   // one group of 16 lanes per (strip, segment)
+    // one group of 16 lanes per (strip, segment); + 2 rows: the first of two fused iterations also writes the rows its second one reads
+    const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
     hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + 15) / 16, nimg), dim3(256), 0, s, imgs);
+    if (any_fused2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + 15) / 16, nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);

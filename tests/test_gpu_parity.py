@@ -382,3 +382,36 @@ def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle):
     for a, b, c in zip(scalar, vector1, vector2):
         assert np.array_equal(a, b)
         assert np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("size", [(400, 300), (777, 531), (257, 300), (56, 64), (57, 9)])
+@pytest.mark.parametrize("layout", ["rgba", "rgb", "gray"])
+def test_two_epf_iterations_run_as_streaming_kernels(gpu_decoder, oracle, size, layout):
+    """Frames with two EPF iterations (distance 1.5 ... 4) decode through filter_stream_kernel (f32 rows out) + filter_stream2_kernel
+    instead of three LDS-tiled stage kernels: against the oracle, and against the stage-by-stage decode of the same stream (the taps
+    switch the fusion off)."""
+    img = synth(size[0], size[1], 9)
+    src = np.ascontiguousarray({"rgba": img, "rgb": img[..., :3], "gray": img[..., 1:2]}[layout])
+    data = oracle.encode(src, distance=2.5, epf_iters=2)
+    ref = oracle.decode(data)
+    assert ref.epf_iters == 2
+    fused = gpu_decode(gpu_decoder, [data])[0]
+    check_pixels(fused, ref.pixels)
+    staged = gpu_decode(gpu_decoder, [data], taps=True)[0]
+    d = np.abs(fused.astype(np.int32) - staged.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+
+
+def test_two_epf_iterations_in_bands(gpu_decoder, oracle):
+    """Band decode of a two-iteration frame: the first streaming kernel also writes the row above and below the band for the second."""
+    import torch
+    from pdn_jpegxl_amd.distributed import decode_frame_band
+    img = synth(600, 1500, 10)
+    data = oracle.encode(img, distance=2.0)
+    assert oracle.decode(data).epf_iters == 2
+    whole = gpu_decode(gpu_decoder, [data])[0]
+    check_pixels(whole, oracle.decode(data).pixels)
+    for world in (2, 3):
+        for rank in range(world):
+            band, (y0, y1) = decode_frame_band(gpu_decoder, data, rank, world)
+            assert np.array_equal(band.cpu().numpy().reshape(y1 - y0, 600, 4), whole[y0:y1]), (world, rank)

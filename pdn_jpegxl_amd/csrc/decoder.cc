@@ -1110,8 +1110,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // (measured at batch 384: LF sections as four such wavefronts per workgroup - 135.7 ms per batch against 125.1 with four lanes of
   // one wavefront: large batches keep the lane layout, the scalar path is for small ones)
   const int direct_lf = global_direct && lf_per_wave == 1, direct_alpha = global_direct && per_alpha_wg == 1;
+  // the lean forms of the LF / alpha kernels (no per-sample Modular path compiled in: two thirds of the registers) when no lossy frame
+  // of the batch can take that path: row-static MA tree, standard predictors, plain ANS codes
+  bool lean_mod = true;
+  for (int i = 0; i < n; i++)
+    if (parse_status[i] == DecoderStatus_Ok && frames[i].encoding == 0 &&
+        (!frames[i].tree_row_static || frames[i].tree_uses_wp || frames[i].mcode.use_prefix || frames[i].mcode.lz77)) lean_mod = false;
   if (!(skip_stages & 1)) {
-  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, direct_lf, s_lf);
+  LaunchLfAns(d_imgs, (const SectionTask*)(d_blob + off_lf_ans_tasks), nlf_ans_t, lf_per_wave, lds_lf <= kLdsMax ? lds_lf : 0, direct_lf, lean_mod, s_lf);
   Mark("lf_ans", s_lf, 0);
   LaunchLfFinish(d_imgs, (const SectionTask*)(d_blob + off_lf_tasks), nlf_t, s_lf);
   LaunchHfBlockList(d_imgs, n, max_groups, s_lf);
@@ -1130,7 +1136,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
   // nothing but the bandwidth-bound pixel stages
   if (any_alpha && !(skip_stages & 4))
-    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, direct_alpha, s_hf);
+    LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, direct_alpha, lean_mod, s_hf);
   Mark("alpha_ans", s_hf, 1);
   if (debug_taps) {   // the quantised coefficients as dense planes (every frame has its own planes in this mode)
     taps.assign(n, Tap());
@@ -1296,7 +1302,7 @@ void JxlHipDecoder::PrepassSingle(ParsedFrame& f, const uint8_t* dev_file) {
   uint64_t lf_end = 0;
   if (e == hipSuccess) {
     const size_t lds = 64 * 128 + 16 + sizeof(DevTreeNode) * f.tree.size() + 8 + 8 * f.mcode.alias.size() + 4 * f.mcode.cfg.size() + f.mcode.ctx_map.size();
-    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, 64, lds <= 150 * 1024 ? lds : 0, 0, own_stream);
+    LaunchLfAns((const DevImage*)(d + o_img), (const SectionTask*)(d + o_task), 1, 64, lds <= 150 * 1024 ? lds : 0, 0, false, own_stream);
     e = hipStreamSynchronize(own_stream);
   }
   if (e == hipSuccess) e = hipMemcpy(st_words, d + o_status, 64, hipMemcpyDeviceToHost);

@@ -748,7 +748,11 @@ struct UniAreas {
 };
 
 // Phase A of one channel on one lane.  Writes residuals (kChanResid), final samples (kChanFinal) or nothing (kChanConst).
-template <bool kLds, bool kUni = false>
+// kGeneric = false: the per-sample path (ModularChannel: weighted predictor, any tree) is not compiled in.  The LF and alpha kernels
+// carry both forms: the generic path alone raises their register allocation by half (lf_ans 156 -> 203 VGPRs, alpha_ans 96 -> 135)
+// whether or not a stream ever takes it, and these wavefronts sit on their registers for tens of milliseconds while the pixel
+// kernels look for room.  The host launches the lean form when every frame of the batch has a row-static tree and plain ANS codes.
+template <bool kLds, bool kUni = false, bool kGeneric = true>
 __device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, const CodeTab<kLds>& tab, typename AS<kLds>::Tree tree, int chan, int sid,
                                   int w, int h, int32_t* out_generic, int stride, ChanDesc* desc, int32_t* wp_scratch = nullptr,
                                   const RowBuf<kLds>* lane_rows = nullptr, const UniAreas* uni = nullptr) {
@@ -771,10 +775,14 @@ __device__ __forceinline__ void DecodeChannelLane(LaneBits& b, uint32_t& state, 
         return;
       }
     }
-    RowBuf<kLds> rbuf;
-    rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
-    if (lane_rows) rbuf = *lane_rows;   // previous row in LDS instead of re-reading the plane (store -> load round trips)
-    ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf, wp_scratch);
+    if constexpr (kGeneric) {
+      RowBuf<kLds> rbuf;
+      rbuf.rb = nullptr; rbuf.rb_stride = 1; rbuf.rb_width = 0;
+      if (lane_rows) rbuf = *lane_rows;   // previous row in LDS instead of re-reading the plane (store -> load round trips)
+      ModularChannel<kLds>(b, state, tab, tree, chan, sid, w, h, out_generic, stride, rbuf, wp_scratch);
+    } else {
+      b.slow_err = 1;   // the host chose the lean form for a stream that needs the other one: reported as a failed section, never decoded wrong
+    }
     *desc = d;
     return;
   }
@@ -913,12 +921,14 @@ __device__ __forceinline__ void GradientTileSteps(JXL_LDS int32_t* trow, const J
                                                   int32_t& W, int32_t& N, int32_t& NW, int32_t& val) {
   const int steps = ncols + nrows - 1;
   const bool top = kTopBand && lane == 0;
-  int32_t r_next = trow[0], up0_next = kTopBand ? 0 : carry_x0[0];
+  int32_t r_next = trow[(0 - lane) & 63], up0_next = kTopBand ? 0 : carry_x0[(0 - lane) & 63];   // column of step 0 (wrapped: see below)
   for (int t = 0; t < steps; t++) {
     const int32_t from_up = FromLaneBelow(val);   // lane r-1's value of the previous step = sample (x, y-1)
     const int c = t - lane;
     const int32_t r = r_next, up0 = up0_next;
-    const int cn = min(max(c + 1, 0), ncols - 1);
+    // lanes outside their row's span read too, at the WRAPPED column: a clamped index would send all of them to one LDS bank
+    // (row pitch 64 words: column k of every row shares a bank), which made this loop slower than the masked reads it replaced
+    const int cn = (c + 1) & 63;
     r_next = trow[cn];
     if (!kTopBand) up0_next = carry_x0[cn];
     if (row_active && (unsigned)c < (unsigned)ncols) {
@@ -1083,7 +1093,7 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // ------------------------------------------------------------------ LF groups, phase A: one lane per LF group
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
-template <bool kLds>
+template <bool kLds, bool kGeneric = true>
 __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1160,7 +1170,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
       else if (i == 5) { w = (int)count; h = 2; stride = (int)count; out = scratch + 2048; }
       else { w = bw; h = bh; stride = bw; out = scratch + 2048 + 2 * 65536; }
     }
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, cd, wps);
+    DecodeChannelLane<kLds, false, kGeneric>(b, state, mt.tab, mt.tree, chan, sid, w, h, out, stride, cd, wps);
   }
   if (!err && (state != 0x130000u || b.slow_err || start_bits + b.Consumed() > (im.sec_off[lf_sec] + im.sec_size[lf_sec]) * 8)) err |= kErrBitstream;
   if (im.single) im.lf_end_bits[0] = start_bits + b.Consumed();
@@ -1730,7 +1740,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
-template <bool kLds>
+template <bool kLds, bool kGeneric = true>
 __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1762,7 +1772,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
     if (im.lz_grp) b.SetLz(im.lz_grp + ((size_t)g << 16), 16, (uint32_t)gw);
     uint32_t state = InitAnsState(b, mt.tab);
     const int sid = 1 + 3 * im.nlf + kNumQuantTables + g;
-    DecodeChannelLane<kLds>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc,
+    DecodeChannelLane<kLds, false, kGeneric>(b, state, mt.tab, mt.tree, 0, sid, gw, gh, im.alpha32 + (size_t)y0 * im.w + x0, im.w, desc,
                             im.wp_grp ? im.wp_grp + (size_t)g * im.wp_grp_ints : nullptr);
     if (state != 0x130000u || b.slow_err) err |= kErrBitstream;
     if (start + b.Consumed() > (im.sec_off[sec] + im.sec_size[sec]) * 8) err |= kErrBitstream;
@@ -2086,9 +2096,12 @@ static void RaiseLds(const void* fn, size_t bytes) {
   if (bytes > 48 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, hipStream_t s) {
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, bool lean, hipStream_t s) {
   if (ntasks <= 0) return;   // slots: sections per workgroup (lanes that decode); lds_bytes: their bit windows + the tables (0: tables stay global)
-  if (lds_bytes) {
+  if (lds_bytes && lean) {   // lean: no frame of the launch needs the per-sample path (see DecodeChannelLane)
+    RaiseLds((const void*)lf_ans_kernel<true, false>, lds_bytes);
+    hipLaunchKernelGGL((lf_ans_kernel<true, false>), dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots, scalar_rows);
+  } else if (lds_bytes) {
     RaiseLds((const void*)lf_ans_kernel<true>, lds_bytes);
     hipLaunchKernelGGL(lf_ans_kernel<true>, dim3(ntasks), dim3(64), lds_bytes, s, imgs, tasks, slots, scalar_rows);
   } else {
@@ -2121,9 +2134,12 @@ void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int
   }
 }
 
-void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, hipStream_t s) {
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, bool lean, hipStream_t s) {
   if (nwg <= 0) return;
-  if (lds_bytes) {
+  if (lds_bytes && lean) {
+    RaiseLds((const void*)alpha_ans_kernel<true, false>, lds_bytes);
+    hipLaunchKernelGGL((alpha_ans_kernel<true, false>), dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride, scalar_rows);
+  } else if (lds_bytes) {
     RaiseLds((const void*)alpha_ans_kernel<true>, lds_bytes);
     hipLaunchKernelGGL(alpha_ans_kernel<true>, dim3(nwg), dim3(64), lds_bytes, s, imgs, tasks, lane_stride, scalar_rows);
   } else {

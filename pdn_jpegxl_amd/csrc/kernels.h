@@ -7,13 +7,13 @@ namespace jxlhip {
 
 // entropy_kernels.hip (lds_bytes == 0 selects the variant that keeps its tables in global memory)
 // LF groups: phase A (ANS, one lane per LF group, one wavefront per image chunk) and phase B (one workgroup per LF group)
-void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, hipStream_t s);
+void LaunchLfAns(const DevImage* imgs, const SectionTask* tasks, int ntasks, int slots, size_t lds_bytes, int scalar_rows, bool lean, hipStream_t s);
 void LaunchLfFinish(const DevImage* imgs, const SectionTask* tasks, int ntasks, hipStream_t s);
 void LaunchHfBlockList(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 size_t HfLaneLdsBytes(int ring_words);
 void LaunchHfDecode(const DevImage* imgs, const SectionTask* tasks, int nwg, int threads, int lane_stride, int ring_words, size_t lds_bytes,
                     size_t lane_bytes, hipStream_t s);
-void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, hipStream_t s);
+void LaunchAlphaAns(const DevImage* imgs, const SectionTask* tasks, int nwg, int lane_stride, size_t lds_bytes, int scalar_rows, bool lean, hipStream_t s);
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s);
 // Modular (lossless) frames: per-section ANS phase + predictor phase; inverse transforms (kind 0 RCT, 1 / 2 horizontal / vertical
 // unsqueeze of planes a (average), b (residual) into c); clamp + interleave

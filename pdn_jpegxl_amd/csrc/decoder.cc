@@ -117,6 +117,7 @@ struct JxlHipDecoder {
   // static tables
   float* d_basis_all = nullptr;
   float* d_basis_small = nullptr;
+  float* d_basis_mfma = nullptr;   // the 32- and 64-point bases laid out per matrix-core lane (tile_kernels.hip: MfmaChainT)
   float* d_llf_scale = nullptr;
   uint16_t* d_natural[kNumOrders] = {};
   U32x2* d_scan[kNumQuantTables] = {};   // per quant table: {order[k], weight bits} in scan order, 3 channels (natural orders, library tables)
@@ -218,6 +219,19 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   for (int c = 1; c <= 32; c *= 2)
     for (int k = 0; k < c; k++)
       for (int nn = 0; nn < c; nn++) small.push_back((float)((k ? std::sqrt(2.0) : 1.0) * std::cos((2 * nn + 1) * k * M_PI / (2.0 * c))));
+  {
+    // for lane (n, q) of a 16x16x4 product over an N-point transform: basis[(4 k + q) * N + n], k = 0 .. N/4-1, contiguous
+    std::vector<float> t;
+    for (int li = 2; li <= 3; li++) {   // N = 32, 64  (st.basis[li]: N = 8 << li)
+      const int N = 8 << li;
+      const std::vector<float>& b = st.basis[li];
+      for (int nn = 0; nn < N; nn++)
+        for (int q = 0; q < 4; q++)
+          for (int k = 0; k < N / 4; k++) t.push_back(b[(size_t)(4 * k + q) * N + nn]);
+    }
+    HIP_OK(hipMalloc(&d_basis_mfma, t.size() * 4));
+    HIP_OK(hipMemcpy(d_basis_mfma, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+  }
   HIP_OK(hipMalloc(&d_basis_small, small.size() * 4));
   HIP_OK(hipMemcpy(d_basis_small, small.data(), small.size() * 4, hipMemcpyHostToDevice));
   HIP_OK(hipMalloc(&d_llf_scale, st.llf_scale.size() * 4));
@@ -251,7 +265,7 @@ JxlHipDecoder::~JxlHipDecoder() {
     if (S.h_blob) (void)hipHostFree(S.h_blob);
     if (S.h_status) (void)hipHostFree(S.h_status);
   }
-  (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_llf_scale);
+  (void)hipFree(d_basis_all); (void)hipFree(d_basis_small); (void)hipFree(d_basis_mfma); (void)hipFree(d_llf_scale);
   for (auto p : d_natural) (void)hipFree(p);
   for (auto p : d_dq) (void)hipFree(p);
   for (auto p : d_scan) (void)hipFree(p);
@@ -1156,7 +1170,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (int c0 = 0; c0 < n; c0 += pixel_chunk) {
     const int cnt = std::min(pixel_chunk, n - c0);
     if (!(skip_stages & 8))
-    LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, s_pix);
+    LaunchReconTiles(d_imgs + c0, cnt, max_tiles, d_basis_all, d_basis_small, d_llf_scale, d_basis_mfma, s_pix);
     Mark("reconstruct", s_pix, 2);   // exactly recon_tile_kernel; one mark per chunk, the per-stage totals add them up
     LaunchExpandCoefficients(d_imgs + c0, cnt, false, max_tiles, s_pix);
     LaunchGenericReconstruct(d_imgs + c0, cnt, d_basis_all, d_basis_small, d_llf_scale, s_pix);

@@ -42,6 +42,29 @@ __device__ __forceinline__ F4 MfmaChain(const float* pa, int sa, const float* pb
   for (int k = 0; k < N / 4; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
   return acc;
 }
+// The same with one operand stream read from the k-contiguous basis table (basis_mfma: for a lane (n, q) the N / 4 values
+// basis[(4 k + q) * N + n], k = 0 .. N/4-1, lie side by side): N / 16 sixteen-byte loads and one address instead of N / 4 loads with
+// an address each (64-point passes: 16 global loads and as many 64-bit address sums per sub-block).
+template <int N, bool kTableIsA>
+__device__ __forceinline__ F4 MfmaChainT(const float* table, const float* po, int so) {
+  float t[N / 4], o[N / 4];
+#pragma unroll
+  for (int k = 0; k < N / 16; k++) {
+    const float4 v = *(const float4*)(table + 4 * k);
+    t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < N / 4; k++) o[k] = po[k * so];
+  F4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < N / 4; k++)
+    acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
+  return acc;
+}
+// offset of the N-point table inside basis_mfma (N = 32, 64), and of lane (n, q)'s run
+__device__ __forceinline__ const float* MfmaTable(const float* basis_mfma, int N, int n, int q) {
+  return basis_mfma + (N == 32 ? 0 : 1024) + (n * 4 + q) * (N / 4);
+}
 __device__ __forceinline__ F4 MfmaChainN(int n, const float* pa, int sa, const float* pb, int sb) {
   return n == 16 ? MfmaChain<16>(pa, sa, pb, sb) : (n == 32 ? MfmaChain<32>(pa, sa, pb, sb) : MfmaChain<64>(pa, sa, pb, sb));
 }
@@ -205,7 +228,7 @@ constexpr int kTileF = kTS * kLP;   // floats of one channel's tile
 //     wavefront 0; LLF of channel t is computed by the first wavefront of team t with lane shuffles while the others scatter.
 //   * 1 / v through v_rcp_f32 (1 ulp; the term is a bias correction <= 0.15 / |v|).
 __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
-                                                             const float* llf_scale) {
+                                                             const float* llf_scale, const float* basis_mfma) {
   extern __shared__ __align__(16) uint8_t smem_raw[];
   float* cfc3 = (float*)smem_raw;                      // 3 * kTileF   coefficients -> columns done -> pixels; team order Y, X, B
   float* B816 = cfc3 + 3 * kTileF;                     // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
@@ -379,9 +402,10 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs
       m[rb] = MfmaSubBlock(inf);   // wave-uniform
       if (m[rb]) {
         const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
-        const float* B = (R == 16 ? B816 + 64 : Bl + (R * R - 64) / 3) + lq * R + iy * 8 + l16;
         const float* cp = cfc + ((rb * 2 - iy) * 8 + lq) * kLP + x0 + l16;
-        acc[rb] = MfmaChainN(R, B, 4 * R, cp, 4 * kLP);
+        if (R == 16) acc[rb] = MfmaChain<16>(B816 + 64 + lq * 16 + iy * 8 + l16, 64, cp, 4 * kLP);
+        else if (R == 32) acc[rb] = MfmaChainT<32, true>(MfmaTable(basis_mfma, 32, iy * 8 + l16, lq), cp, 4 * kLP);
+        else acc[rb] = MfmaChainT<64, true>(MfmaTable(basis_mfma, 64, iy * 8 + l16, lq), cp, 4 * kLP);
       }
     }
     // the rest on the vector ALUs.  One lane = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
@@ -431,9 +455,10 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs
       m[cs] = MfmaSubBlock(inf);
       if (m[cs]) {
         const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
-        const float* B = (C == 16 ? B816 + 64 : Bl + (C * C - 64) / 3) + lq * C + ix * 8 + l16;
         const float* ap = cfc + (y0 + l16) * kLP + (cs * 2 - ix) * 8 + lq;
-        acc[cs] = MfmaChainN(C, ap, 4, B, 4 * C);
+        if (C == 16) acc[cs] = MfmaChain<16>(ap, 4, B816 + 64 + lq * 16 + ix * 8 + l16, 64);
+        else if (C == 32) acc[cs] = MfmaChainT<32, false>(MfmaTable(basis_mfma, 32, ix * 8 + l16, lq), ap, 4);
+        else acc[cs] = MfmaChainT<64, false>(MfmaTable(basis_mfma, 64, ix * 8 + l16, lq), ap, 4);
       }
     }
     // the rest: two adjacent rows per lane
@@ -908,12 +933,12 @@ __global__ void out_only_kernel(const DevImage* imgs) {
 }
 
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
-                      const float* llf_scale, hipStream_t s) {
+                      const float* llf_scale, const float* basis_mfma, hipStream_t s) {
   // three tiles, B816, four per-cell words + 2 x 3 prefix words per cell, totals, per-cell scan-list pointers
   const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128) * 4;
   static bool raised = false;
   if (!raised) { (void)hipFuncSetAttribute((const void*)recon_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
-  hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale);
+  hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale, basis_mfma);
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,

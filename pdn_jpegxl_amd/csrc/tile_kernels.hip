@@ -82,6 +82,12 @@ __device__ __forceinline__ float SrgbOetfT(float v) {
   const float cur = 1.055f * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - 0.055f;
   return v <= 0.0031308f ? lin : cur;
 }
+// the same curve scaled to 0 .. 255 (the 8-bit output path)
+__device__ __forceinline__ float SrgbOetf255T(float v) {
+  const float lin = (12.92f * 255.0f) * v;
+  const float cur = (1.055f * 255.0f) * __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(v) * (1.0f / 2.4f)) - (0.055f * 255.0f);
+  return v <= 0.0031308f ? lin : cur;
+}
 __device__ __forceinline__ float PowT(float a, float e) { return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(a) * e); }   // a > 0
 // Encoded value from display-linear, sign-symmetric like the reference's library.  kind: 0 linear, 1 sRGB, 2 BT.709, 3 PQ,
 // 5 table (4096 entries over sqrt(linear), clamped to [0, 1]: an evaluated ICC tone curve).
@@ -656,8 +662,16 @@ __device__ __forceinline__ uint32_t PixelToRgba8(const DevImage& im, float X, fl
   float r = im.opsin_inv[0] * mr + im.opsin_inv[1] * mg + im.opsin_inv[2] * mb;
   float g = im.opsin_inv[3] * mr + im.opsin_inv[4] * mg + im.opsin_inv[5] * mb;
   float bl = im.opsin_inv[6] * mr + im.opsin_inv[7] * mg + im.opsin_inv[8] * mb;
-  if (im.to_srgb) { r = SrgbOetfT(r); g = SrgbOetfT(g); bl = SrgbOetfT(bl); }
-  return (uint32_t)ToU8T(r) | (uint32_t)ToU8T(g) << 8 | (uint32_t)ToU8T(bl) << 16 | a << 24;
+  // to 8 bits with v_cvt_pk_u8_f32: converts (round to nearest, ties to even - tools/cvt_probe.hip), saturates to 0 .. 255, maps NaN to
+  // 0 and inserts the byte, in ONE instruction per channel instead of scale / max / min / add / convert / shift / or; the * 255 is
+  // folded into the transfer curve's constants.  (Differs from round-half-up only on exact ties.)
+  if (im.to_srgb) { r = SrgbOetf255T(r); g = SrgbOetf255T(g); bl = SrgbOetf255T(bl); }
+  else { r *= 255.0f; g *= 255.0f; bl *= 255.0f; }
+  uint32_t px = a << 24;
+  px = __builtin_amdgcn_cvt_pk_u8_f32(r, 0, px);
+  px = __builtin_amdgcn_cvt_pk_u8_f32(g, 1, px);
+  px = __builtin_amdgcn_cvt_pk_u8_f32(bl, 2, px);
+  return px;
 }
 
 // Rolling windows of one lane, as four slots each, indexed by (row & 3) with COMPILE-TIME phases (the row loop is unrolled by four):

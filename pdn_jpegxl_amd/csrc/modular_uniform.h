@@ -38,6 +38,15 @@ __device__ __forceinline__ int32_t UWriteLane(int32_t v, uint32_t lane, int32_t 
 __device__ __forceinline__ int64_t UAbs64(int64_t v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int UFloorLog2_64(uint64_t v) { return 63 - __builtin_clzll(v); }   // v > 0
 
+// Sum over the four lanes of a quad, left in all four (two DPP quad permutes).
+__device__ __forceinline__ uint32_t UQuadSum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm:[1,0,3,2] */, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E /* quad_perm:[2,3,0,1] */, 0xF, 0xF, false);
+  return v;
+}
+// vdiv[idx] with a per-lane index (ds_bpermute: the LDS crossbar, no LDS memory)
+__device__ __forceinline__ uint32_t ULaneTable(int32_t table, uint32_t idx) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx << 2), table); }
+
 struct UniLeaf {   // one grid cell / one leaf
   uint32_t pred, cl, mul;
   int32_t off;
@@ -132,6 +141,15 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
     if (__builtin_expect(s_n <= 32, 0)) { s_buf |= (uint64_t)JXL_RFL(ring[__umul24(s_rd & (kRingWords - 1), ring_rs)]) << s_n; s_n += 32; s_rd++; }
   };
   bool big = false;   // a sample (or an error of the weighted predictor) beyond the bound of the 32-bit forms has been seen
+  // Weighted predictor, 32-bit form: its four sub-predictors are four lanes (lane & 3; every quad computes the same).  Per lane: the
+  // coefficients of ITS prediction over (W, N, NE) and over the true errors (West, N, NW, NE) - the format's four formulas as one -
+  // its maximum weight, its two error rows in LDS.
+  const int vi = lane & 3;
+  const uint32_t vmaxw = vi == 0 ? 13u : 12u;
+  const int32_t paW = (vi == 0 || vi == 2) ? 1 : 0, paN = vi == 0 ? -1 : (vi == 2 ? 0 : 1), paNE = vi == 0 ? 1 : 0;
+  const int32_t pkW = vi == 1 ? 16 : (vi == 2 ? 10 : 0), pkN = vi == 1 ? 16 : (vi == 2 ? 10 : (vi == 3 ? 7 : 0)),
+                pkNW = vi == 2 ? 10 : (vi == 3 ? 7 : 0), pkNE = vi == 1 ? 16 : (vi == 3 ? 7 : 0);
+  JXL_LDS int32_t* const pe_lane = kWp ? c.wpe + (size_t)vi * 2 * w2 : nullptr;
   for (int y = 0; y < h; y++) {
     JXL_LDS int32_t* const cur = c.rows + (y % 3) * rw;
     JXL_LDS int32_t* const prv = c.rows + ((y + 2) % 3) * rw;
@@ -144,6 +162,13 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
     // e_prev[i] = the error that sample adds to this one's slot "N"; teW / teN_prev likewise for the true errors
     uint32_t wA_prev[4] = {0, 0, 0, 0}, e_prev[4] = {0, 0, 0, 0};
     int32_t teW = 0, teN_prev = 0;
+    // the same per lane (32-bit form): error of the row above at x and x + 1, slot "N" sum and error of the sample before
+    int32_t ven = 0, vene = 0;
+    uint32_t vA_prev = 0, ve_prev = 0;
+    if constexpr (kWp) {
+      ven = pe_lane[prev_o];
+      vene = pe_lane[prev_o + 1];
+    }
     for (int x0 = 0; x0 < w; x0 += 64) {
       const int cnt = min(64, w - x0);
       // ---- per-batch vector loads: the neighbours of 64 samples
@@ -162,7 +187,7 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
         vTe = xl < w ? c.werr[prev_o + xl] : 0;
         vTene = xl + 1 < w ? c.werr[prev_o + xl + 1] : 0;
       }
-      int32_t vout = 0, vEo[4] = {0, 0, 0, 0}, vTo = 0;
+      int32_t vout = 0, vTo = 0;
       if (x0 == 0) {   // start of the row: West, North and North-West are the sample above (0 in the top row)
         W = y ? UReadLane(vN0, 0) : 0;
         N = W; NW = W; WW = W;
@@ -182,42 +207,37 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
           int64_t wp_pred = 0, wpred8 = 0;
           int32_t wp_err = 0;
           int64_t prediction[4] = {0, 0, 0, 0};
+          int32_t vp = 0;      // (32-bit form) this lane's sub-prediction
+          uint32_t vA = 0;     // ... and its slot "N" error sum
+          uint32_t A[4] = {0, 0, 0, 0};   // (64-bit form) the same, scalar
           if constexpr (kWp) {
-            uint32_t weights[4], A[4];
+            uint32_t weights[4];
             const int32_t teN = UReadLane(vTe, (uint32_t)li);
             const int32_t teNE = x + 1 < w ? UReadLane(vTene, (uint32_t)li) : teN;
             const int32_t teNW = x > 0 ? teN_prev : teN;
             const int32_t tW = x > 0 ? teW : 0;
             if (__builtin_expect(!big, 1)) {
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                const uint32_t en = (uint32_t)UReadLane(vE[i], (uint32_t)li);
-                A[i] = en + (x > 0 ? e_prev[i] : 0u);
-                const uint32_t ene = x + 1 < w ? (uint32_t)UReadLane(vEne[i], (uint32_t)li) : A[i];
-                const uint32_t enw = x > 0 ? wA_prev[i] : A[i];
-                const uint32_t s3 = A[i] + ene + enw;
-                int shift = (31 - __builtin_clz(s3 + 1)) - 5;
-                if (shift < 0) shift = 0;
-                const uint32_t maxw = i == 0 ? 13u : 12u;
-                weights[i] = 4 + ((maxw * (uint32_t)UReadLane(c.vdiv, s3 >> shift)) >> shift);
-              }
+              // four lanes, one sub-predictor each
+              vA = (uint32_t)ven + ve_prev;                                   // ve_prev is 0 at the start of a row
+              const uint32_t ene = x + 1 < w ? (uint32_t)vene : vA;
+              const uint32_t enw = x > 0 ? vA_prev : vA;
+              const uint32_t s3 = vA + ene + enw;
+              const int sh = max(26 - (int)__clz(s3 + 1), 0);
+              uint32_t wgt = 4 + ((vmaxw * ULaneTable(c.vdiv, s3 >> sh)) >> sh);
+              const uint32_t wsum = UQuadSum(wgt);
+              wgt >>= (31 - (int)__clz(wsum)) - 4;
+              const uint32_t wsum2 = UQuadSum(wgt);
               const int32_t N8 = N << 3, W8 = W << 3, NE8 = NE << 3;
-              const int32_t sumWN = teN + tW;
+              // (24-bit multiplies: full rate; under the 32-bit form's bound the samples * 8 stay below 2^21 and the errors below 2^22)
+              vp = __mul24(paW, W8) + __mul24(paN, N8) + __mul24(paNE, NE8) -
+                   ((__mul24(pkW, tW) + __mul24(pkN, teN) + __mul24(pkNW, teNW) + __mul24(pkNE, teNE)) >> 5);
+              const int32_t acc = (int32_t)UQuadSum((uint32_t)(vp * (int32_t)wgt)) + (int32_t)(wsum2 >> 1) - 1;
+              int32_t wq = (int32_t)JXL_RFL((uint32_t)(int32_t)(((int64_t)acc * (int64_t)ULaneTable(c.vdiv, wsum2 - 1)) >> 24));
               int32_t pm = tW;
               if (abs(teN) > abs(pm)) pm = teN;
               if (abs(teNW) > abs(pm)) pm = teNW;
               if (abs(teNE) > abs(pm)) pm = teNE;
               wp_err = pm;
-              const int32_t p0 = W8 + NE8 - N8, p1 = N8 - (((sumWN + teNE) * 16) >> 5), p2 = W8 - (((sumWN + teNW) * 10) >> 5),
-                            p3 = N8 - ((teNW * 7 + teN * 7 + teNE * 7) >> 5);
-              prediction[0] = p0; prediction[1] = p1; prediction[2] = p2; prediction[3] = p3;
-              uint32_t wsum = weights[0] + weights[1] + weights[2] + weights[3];
-              const int lw = 31 - __builtin_clz(wsum);
-              wsum = 0;
-#pragma unroll
-              for (int i = 0; i < 4; i++) { weights[i] >>= lw - 4; wsum += weights[i]; }
-              const int32_t sum = (int32_t)(wsum >> 1) - 1 + p0 * (int32_t)weights[0] + p1 * (int32_t)weights[1] + p2 * (int32_t)weights[2] + p3 * (int32_t)weights[3];
-              int32_t wq = (int32_t)(((int64_t)sum * (int64_t)(uint32_t)UReadLane(c.vdiv, wsum - 1)) >> 24);
               if (((teN ^ tW) | (teN ^ teNW)) <= 0) {
                 const int32_t mx = max(W8, max(NE8, N8)), mn = min(W8, min(NE8, N8));
                 wq = wq < mn ? mn : (wq > mx ? mx : wq);
@@ -263,8 +283,6 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
               }
               wp_pred = (wpred8 + 3) >> 3;
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) wA_prev[i] = A[i];
             teN_prev = teN;
           }
           // ---- leaf
@@ -381,34 +399,37 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
           }
           const int32_t val = (int32_t)((int64_t)UnpackSigned(u) * (int64_t)l_mul + l_off + guess);
           vout = UWriteLane(val, (uint32_t)li, vout);
-          big = big || (uint32_t)(val + (1 << 18)) >= (1u << 19);   // the bound of the 32-bit forms (properties, weighted predictor)
           if constexpr (kWp) {
-            int32_t terr;
-            // (the sample just decoded is the one value not yet checked - `big` was raised for it above: its own update already
-            // takes the 64-bit form when it is large)
-            if (__builtin_expect(!big, 1)) {
+            const int64_t v8l = (int64_t)val << 3;
+            const int32_t terr = (int32_t)(wpred8 - v8l);
+            // the bound the 32-bit form relies on, checked on every value the later samples will read back (this sample's own update
+            // already takes the 64-bit form when it is the first large one)
+            const bool big_new = big || (uint32_t)(val + (1 << 18)) >= (1u << 19) || (uint32_t)(terr + (1 << 22)) >= (1u << 23);
+            if (__builtin_expect(!big_new, 1)) {
               const int32_t v8 = val << 3;
-              terr = (int32_t)wpred8 - v8;
-#pragma unroll
-              for (int i = 0; i < 4; i++) {
-                const uint32_t e = (uint32_t)(abs((int32_t)prediction[i] - v8) + 3) >> 3;
-                vEo[i] = UWriteLane((int32_t)e, (uint32_t)li, vEo[i]);
-                e_prev[i] = e;
-              }
+              const uint32_t ve = (uint32_t)(abs(vp - v8) + 3) >> 3;
+              if (lane < 4) pe_lane[cur_o + x] = (int32_t)ve;
+              vA_prev = vA; ve_prev = ve;
+              ven = vene;
+              vene = x + 2 < w ? pe_lane[prev_o + x + 2] : 0;     // for the sample after the next: off the chain
             } else {
-              const int64_t v8 = (int64_t)val << 3;
-              terr = (int32_t)(wpred8 - v8);
+              if (!big) {   // the switch: this sample was predicted on the lanes; from here on the state lives in scalar registers
+#pragma unroll
+                for (int i = 0; i < 4; i++) { prediction[i] = UReadLane(vp, (uint32_t)i); A[i] = (uint32_t)UReadLane((int32_t)vA, (uint32_t)i); }
+              }
 #pragma unroll
               for (int i = 0; i < 4; i++) {
-                const uint32_t e = (uint32_t)((UAbs64(prediction[i] - v8) + 3) >> 3);
-                vEo[i] = UWriteLane((int32_t)e, (uint32_t)li, vEo[i]);
+                const uint32_t e = (uint32_t)((UAbs64(prediction[i] - v8l) + 3) >> 3);
+                if (lane == i) (c.wpe + (size_t)i * 2 * w2 + cur_o)[x] = (int32_t)e;
                 e_prev[i] = e;
+                wA_prev[i] = A[i];
               }
             }
+            big = big_new;
             vTo = UWriteLane(terr, (uint32_t)li, vTo);
             teW = terr;
-            // the bound the 32-bit form relies on, checked on every value the later samples will read back
-            big = big || (uint32_t)(terr + (1 << 22)) >= (1u << 23);
+          } else {
+            big = big || (uint32_t)(val + (1 << 18)) >= (1u << 19);   // the bound of the 32-bit property sums
           }
           prev9 = (int64_t)W + N - NW;
           const int32_t oldW = W;
@@ -421,11 +442,7 @@ __device__ __forceinline__ void UniRows(UniCtx& c, LaneBits& b) {
       if (lane < cnt) {
         row[x0 + lane] = vout;
         cur[x0 + lane] = vout;
-        if constexpr (kWp) {
-          c.werr[cur_o + x0 + lane] = vTo;
-#pragma unroll
-          for (int i = 0; i < 4; i++) (c.wpe + (size_t)i * 2 * w2 + cur_o)[x0 + lane] = vEo[i];
-        }
+        if constexpr (kWp) c.werr[cur_o + x0 + lane] = vTo;   // (the sub-predictor errors were stored sample by sample)
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();

@@ -1077,7 +1077,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       uint32_t* order = (uint32_t*)(h_blob + order_off);
       const size_t sec0 = f.single ? 0 : 2 + (size_t)f.nlf + (size_t)pass * f.ng;
       for (uint32_t g = hg0; g < hg1; g++) order[g - hg0] = g;
-      if (!f.single)
+      if (!f.single && !Knob("JXLHIP_NO_HF_SORT"))   // (experiment knob: measured effect of the order, profiles/r03_hf_sort_ab.txt)
         std::stable_sort(order, order + (hg1 - hg0), [&](uint32_t a, uint32_t b) { return f.sec_size[sec0 + a] > f.sec_size[sec0 + b]; });
       rec.hf_order = (const uint32_t*)(d_blob + order_off);
       for (uint32_t j = 0; j < hg1 - hg0; j += pw) {

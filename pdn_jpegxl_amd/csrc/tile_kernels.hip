@@ -6,7 +6,7 @@
 //                         >= 16 points on v_mfma_f32_16x16x4_f32), f32 XYB out (12 B/px).  Tiles that hold part of a varblock larger
 //                         than the tile, a special 8x8 transform or a progressive frame go to a per-image list for the generic
 //                         (unfused, any-size) kernels of kernels.hip.
-//   filter_stream_kernel  Gaborish + one / two EPF iterations + XYB -> output samples in one register-streaming kernel (DPP row shifts).
+//   filter_stream_kernel  Gaborish + one / two EPF iterations + XYB -> output samples in one register-streaming kernel (DPP wave shifts).
 //   filter_tile_kernel    one Gaborish / EPF stage on a 64x32 tile + halo staged in LDS (mirrored at the frame edge); the LAST
 //                         enabled stage of an image converts XYB -> output samples and merges alpha.  Used for what the streaming
 //                         kernel does not cover.
@@ -615,21 +615,24 @@ __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) 
   }
 }
 
-// Gaborish + EPF pass 1 (the only pass of epf_iters == 1) + XYB -> output samples in one kernel, WITHOUT LDS: a group of 16 lanes
-// (one DPP row) owns a strip of 64 columns (16 quads of 4 pixels; the outer quad each side is halo, 56 columns are output) and walks
+// Gaborish + EPF pass 1 (the only pass of epf_iters == 1) + XYB -> output samples in one kernel, WITHOUT LDS: a wavefront owns a
+// strip of 256 columns (64 quads of 4 pixels; the outer quad each side is halo, 248 columns are output) and walks
 // down a segment of rows.  Every lane keeps the rolling windows of its quad in registers - two input rows with their horizontal
 // neighbour sums, three Gaborish rows, three rows of vertical and of horizontal channel-weighted differences - and gets its
-// horizontal neighbours from the lanes beside it by DPP row shifts (v_mov_dpp row_shr / row_shl: one VALU op, no LDS round trip).
+// horizontal neighbours from the lanes beside it by DPP wave shifts (v_mov_dpp wave_shr / wave_shl: one VALU op, no LDS round trip).
 // Per input row a lane issues three 16-byte loads (256 contiguous bytes per group and plane), one row ahead of their use; per
 // output row one 16-byte store.  The LDS-tiled version read ~75 LDS words per pixel (37 % of its LDS cycles bank conflicts) and
 // re-read a 38 x 40 footprint per 32 x 32 tile (1.48x); this one reads 64 / 56 x 70 / 64 = 1.25x and is bound by its VALU work.
-constexpr int kStripOut = 56;    // output columns of a strip (14 quads)
-constexpr int kSegRows = 64;     // output rows of a segment (+ 3 halo rows each side)
+constexpr int kStripLanes = 64;                    // lanes of a strip: a whole wavefront (DPP wave shifts cross the rows of 16)
+constexpr int kStripOut = 4 * (kStripLanes - 2);   // output columns of a strip: every lane's quad but the two halo quads at its ends (248;
+                                                   // with strips of one DPP row - 16 lanes, 56 of 64 columns - a seventh of the work was halo)
+constexpr int kGroupsPerWg = 256 / kStripLanes;
+constexpr int kSegRows = 128;    // output rows of a segment (+ 3 halo rows each side)
 __device__ __forceinline__ float DppFromLeft(float v) {    // value of lane - 1 inside the row of 16 (lane 0: 0)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111 /* row_shr:1 */, 0xF, 0xF, true));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138 /* wave_shr:1 */, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float DppFromRight(float v) {   // value of lane + 1 inside the row of 16 (lane 15: 0)
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101 /* row_shl:1 */, 0xF, 0xF, true));
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130 /* wave_shl:1 */, 0xF, 0xF, true));
 }
 __device__ __forceinline__ F4 ShiftFromLeft(F4 v) { return F4{DppFromLeft(v.w), v.x, v.y, v.z}; }      // element x - 1
 __device__ __forceinline__ F4 ShiftFromRight(F4 v) { return F4{v.y, v.z, v.w, DppFromRight(v.x)}; }    // element x + 1
@@ -790,18 +793,18 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
   const int band_lo = k.to_float ? max(0, im.band_y0 - 1) : im.band_y0, band_hi = k.to_float ? min(k.h, im.band_y1 + 1) : im.band_y1;
   const int band_rows = band_hi - band_lo;
   const int segs = (band_rows + kSegRows - 1) / kSegRows;
-  if ((int)blockIdx.x * 16 >= strips * segs) return;   // whole workgroup past the end
+  if ((int)blockIdx.x * kGroupsPerWg >= strips * segs) return;   // whole workgroup past the end
   // every lane stays in the loop (DPP reads neighbouring lanes); groups past the end repeat the last task and store nothing
-  const int gidx = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int gidx = blockIdx.x * kGroupsPerWg + (threadIdx.x / kStripLanes);
   const bool task = gidx < strips * segs;
   const int gi = task ? gidx : strips * segs - 1;
   const int strip = gi % strips, seg = gi / strips;
-  const int q = threadIdx.x & 15;
+  const int q = threadIdx.x & (kStripLanes - 1);
   k.X = strip * kStripOut - 4 + 4 * q;           // first column of this lane's quad
   k.y0 = band_lo + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, band_hi);
   k.r_end = k.y1 + 3;
   k.interior = k.X >= 0 && k.X + 3 < k.w;
-  k.stores = task && q >= 1 && q <= 14 && k.X < k.w;
+  k.stores = task && q >= 1 && q <= kStripLanes - 2 && k.X < k.w;
   k.full_quad = k.X + 3 < k.w;
   k.in0 = (const JXL_GLOBAL float*)im.stage_in[0][0];
   k.in1 = (const JXL_GLOBAL float*)im.stage_in[0][1];
@@ -839,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
 
 // The second EPF iteration (frames with two: distance 1.5 ... 4) + XYB -> output samples, register streaming like the kernel above
 // but much lighter: three rows of the first iteration's output (f32 planes), four neighbours, a one-pixel SAD.  Same strip geometry
-// (a DPP row of 16 lanes = 64 columns, the outer quads are halo), same output paths.  With it a two-iteration frame runs
+// (a wavefront = 256 columns, the outer quads are halo), same output paths.  With it a two-iteration frame runs
 // reconstruction -> two streaming kernels instead of three LDS-tiled stage kernels (measured, 384 4K frames at distance 2:
 // filters + output 104.8 ms before).
 __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* imgs) {
@@ -849,16 +852,16 @@ __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* img
   const int strips = (w + kStripOut - 1) / kStripOut;
   const int band_rows = im.band_y1 - im.band_y0;
   const int segs = (band_rows + kSegRows - 1) / kSegRows;
-  if ((int)blockIdx.x * 16 >= strips * segs) return;
-  const int gidx = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if ((int)blockIdx.x * kGroupsPerWg >= strips * segs) return;
+  const int gidx = blockIdx.x * kGroupsPerWg + (threadIdx.x / kStripLanes);
   const bool task = gidx < strips * segs;
   const int gi = task ? gidx : strips * segs - 1;
   const int strip = gi % strips, seg = gi / strips;
-  const int q = threadIdx.x & 15;
+  const int q = threadIdx.x & (kStripLanes - 1);
   const int X = strip * kStripOut - 4 + 4 * q;
   const int y0 = im.band_y0 + seg * kSegRows, y1 = min(y0 + kSegRows, im.band_y1);
   const bool interior = X >= 0 && X + 3 < w;
-  const bool stores = task && q >= 1 && q <= 14 && X < w;
+  const bool stores = task && q >= 1 && q <= kStripLanes - 2 && X < w;
   const bool full_quad = X + 3 < w;
   const JXL_GLOBAL float* in0 = (const JXL_GLOBAL float*)im.stage_out[0][0];
   const JXL_GLOBAL float* in1 = (const JXL_GLOBAL float*)im.stage_out[0][1];
@@ -960,10 +963,10 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
-    // one group of 16 lanes per (strip, segment); + 2 rows: the first of two fused iterations also writes the rows its second one reads
+    // one wavefront per (strip, segment); + 2 rows: the first of two fused iterations also writes the rows its second one reads
     const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
-    hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + 15) / 16, nimg), dim3(256), 0, s, imgs);
-    if (any_fused2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + 15) / 16, nimg), dim3(256), 0, s, imgs);
+    hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
+    if (any_fused2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);

@@ -195,15 +195,31 @@ JxlHipDecoder::JxlHipDecoder(int dev) {
   HIP_OK(hipSetDevice(device));
   // (measured on MI355X, batch 384: stream priorities and CU masks that confine the entropy streams to part of the chip change
   // nothing or lose - the three chains already add up to the chip's capacity)
-  HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
+  // JXLHIP_ENTROPY_CUS=N (experiments build): the two entropy streams may only use N of the 256 CUs (the mask's bits go round the
+  // XCDs, so N / 8 per XCD); JXLHIP_PIXEL_CUS=M: this object's own stream keeps off the first 256 - M.
+  int entropy_cus = 0, pixel_cus = 0;
+  if (const char* e = Knob("JXLHIP_ENTROPY_CUS")) entropy_cus = std::min(256, std::max(0, atoi(e)));
+  if (const char* e = Knob("JXLHIP_PIXEL_CUS")) pixel_cus = std::min(256, std::max(0, atoi(e)));
+  auto masked_stream = [](hipStream_t* s, int first, int count) {
+    uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = first; i < first + count; i++) mask[i >> 5] |= 1u << (i & 31);
+    HIP_OK(hipExtStreamCreateWithCUMask(s, 8, mask));
+  };
+  if (pixel_cus) masked_stream(&own_stream, 256 - pixel_cus, pixel_cus);
+  else HIP_OK(hipStreamCreateWithFlags(&own_stream, hipStreamNonBlocking));
   // The entropy chains are latency-bound (a kernel lasts as long as its longest section) and need few wavefronts, but ALL of them at
   // once: while their workgroups queue behind a pixel kernel's thousands of short ones, an entropy kernel runs in rounds and takes a
   // multiple of its time.  Their streams get the highest priority, so that their workgroups take the next free slots.
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
   const int prio = Knob("JXLHIP_NO_PRIORITY") ? prio_least : prio_greatest;
-  HIP_OK(hipStreamCreateWithPriority(&stream_lf, hipStreamNonBlocking, prio));
-  HIP_OK(hipStreamCreateWithPriority(&stream_hf, hipStreamNonBlocking, prio));
+  if (entropy_cus) {
+    masked_stream(&stream_lf, 0, entropy_cus);
+    masked_stream(&stream_hf, 0, entropy_cus);
+  } else {
+    HIP_OK(hipStreamCreateWithPriority(&stream_lf, hipStreamNonBlocking, prio));
+    HIP_OK(hipStreamCreateWithPriority(&stream_hf, hipStreamNonBlocking, prio));
+  }
   for (auto& S : slots) {
     HIP_OK(hipEventCreateWithFlags(&S.lf_done, hipEventDisableTiming));
     HIP_OK(hipEventCreateWithFlags(&S.hf_done, hipEventDisableTiming));
@@ -645,14 +661,18 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // Sections per workgroup, per image: the HF kernel's LDS is the image's code tables (30 .. 60 KB: they double with the alias-table
   // width) plus 288 B per lane, and a launch has ONE LDS size.  Sized by the batch-wide maximum, a single image with wide tables
   // pushed every workgroup from two per CU to one (hf_decode 30 -> 58 ms at batch 384); instead every image gets as many lanes per
-  // workgroup as fit beside ITS tables in half a CU's LDS (whole wavefronts; images with wide tables use more, smaller workgroups).
+  // workgroup as fit beside ITS tables in the budget (whole wavefronts; images with wide tables use more, smaller workgroups).
+  // The budget: LDS is what the three pipelined chains compete for (profiles/r03_experiment_cu_masks.txt: confined to N CUs the
+  // HF kernel takes 12 700 CU-ms / N, it is bound by resident workgroups, not by latency).  With 80 KB a 4K frame (135 sections,
+  // ~50 KB of tables) needed two workgroups of 77 KB, each with its own copy of the tables; 112 KB holds the frame in one of 96 KB and
+  // leaves room for one reconstruction workgroup beside it: step 123 -> 115 ms (profiles/r03_experiment_hf_lds_budget.txt).
   auto hf_code_bytes = [](const HostCode& c) { return 8 + 8 * c.alias.size() + 4 * c.cfg.size() + c.ctx_map.size() + 64 + 32; };
   auto hf_table_bytes = [&](const ParsedFrame& f) {   // the widest of the frame's passes
     size_t b = hf_code_bytes(f.acode);
     for (auto& ep : f.extra_passes) b = std::max(b, hf_code_bytes(ep.acode));
     return b;
   };
-  size_t kHfLdsTarget = 80 * 1024;
+  size_t kHfLdsTarget = 112 * 1024;
   if (const char* e = Knob("JXLHIP_HF_LDS_KB")) { const int kb = atoi(e); if (kb >= 32 && kb <= 160) kHfLdsTarget = (size_t)kb * 1024; }   // experiment knob
   auto hf_per_wg = [&](const ParsedFrame& f) {
     // the fewest workgroups whose (tables + lanes) fit the budget, the image's sections spread evenly over them: every workgroup

@@ -32,6 +32,17 @@ __device__ const uint8_t d_nnz_ctx[64] = {0,   0,   31,  62,  62,  93,  93,  93,
 __device__ __forceinline__ int CeilLog2D(uint32_t x) { return x <= 1 ? 0 : 32 - __clz(x - 1); }
 __device__ __forceinline__ int32_t UnpackSigned(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1); }
 // who: 1 lf_ans, 2 lf_finish, 3 hf_decode, 4 alpha_ans, 5 modular; where: section index (diagnostics: status[2 + who] = where + 1)
+// Wavefront issue priority (s_setprio) of the serial decoders, for tools/ab_prio.sh.  Measured in the pipelined step (round 3):
+// raising it changes nothing (123-125 ms at 0, 1 and 3), so the default emits no instruction.
+#ifndef JXLHIP_PRIO_SERIAL
+#define JXLHIP_PRIO_SERIAL 0
+#endif
+#if JXLHIP_PRIO_SERIAL
+#define JXL_SERIAL_PRIO() __builtin_amdgcn_s_setprio(JXLHIP_PRIO_SERIAL)
+#else
+#define JXL_SERIAL_PRIO() ((void)0)
+#endif
+
 __device__ __forceinline__ void SetError(const DevImage& im, uint32_t bits, int who = 0, int where = 0) {
   atomicOr(im.status, bits);
   if (who) im.status[2 + who] = (uint32_t)where + 1;
@@ -1095,6 +1106,7 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds, bool kGeneric = true>
 __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int scalar_rows) {
+  JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
@@ -1421,6 +1433,7 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
 // (the task's section count rounded up to four: every workgroup uses what ITS image's tables leave of the launch's LDS).
 template <bool kLds, int kRing>
 __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
+  JXL_SERIAL_PRIO();
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
   typedef LaneBitsT<kRing, kRing / 4> Bits;
@@ -1742,6 +1755,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds, bool kGeneric = true>
 __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
+  JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];
@@ -1867,6 +1881,7 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // LDS of that shape: bit windows | 3 rows | weighted-predictor rows | grid | tree + code.
 template <bool kLds, bool kUni = false>
 __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
+  JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
   const DevImage& im = imgs[task.image];

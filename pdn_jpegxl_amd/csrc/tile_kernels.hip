@@ -18,6 +18,17 @@
 
 namespace jxlhip {
 
+// Wavefront issue priority of the pixel kernels, for tools/ab_prio.sh.  Measured in the pipelined step (round 3): 1 or 3 make
+// the streaming filters slower (filters + output 51 -> 82 ms per batch, step 123 -> 148 ms), so the default emits no instruction.
+#ifndef JXLHIP_PRIO_PIXEL
+#define JXLHIP_PRIO_PIXEL 0
+#endif
+#if JXLHIP_PRIO_PIXEL
+#define JXL_PIXEL_PRIO() __builtin_amdgcn_s_setprio(JXLHIP_PRIO_PIXEL)
+#else
+#define JXL_PIXEL_PRIO() ((void)0)
+#endif
+
 namespace {
 
 constexpr int kTS = 64;       // tile side
@@ -235,6 +246,7 @@ constexpr int kTileF = kTS * kLP;   // floats of one channel's tile
 //   * 1 / v through v_rcp_f32 (1 ulp; the term is a bias correction <= 0.15 / |v|).
 __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
                                                              const float* llf_scale, const float* basis_mfma) {
+  JXL_PIXEL_PRIO();
   extern __shared__ __align__(16) uint8_t smem_raw[];
   float* cfc3 = (float*)smem_raw;                      // 3 * kTileF   coefficients -> columns done -> pixels; team order Y, X, B
   float* B816 = cfc3 + 3 * kTileF;                     // 320  IDCT bases of the two common sizes (N = 8 at 0, N = 16 at 64)
@@ -521,6 +533,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs
 // kStage: 0 Gaborish, 1 EPF pass 0, 2 EPF pass 1, 3 EPF pass 2.  Tile = 64 x 32 output pixels.
 template <int kStage>
 __global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) {
+  JXL_PIXEL_PRIO();
   constexpr int TW = 64, TH = 32;
   constexpr int HALO = kStage == 0 ? 1 : (kStage == 1 ? 3 : (kStage == 2 ? 2 : 1));
   constexpr int LW = TW + 2 * HALO, LH = TH + 2 * HALO;
@@ -783,6 +796,7 @@ __device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst&
 }
 
 __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* imgs) {
+  JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
   if (!im.fused_gab_epf1) return;
   StreamConst k;
@@ -846,6 +860,7 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
 // reconstruction -> two streaming kernels instead of three LDS-tiled stage kernels (measured, 384 4K frames at distance 2:
 // filters + output 104.8 ms before).
 __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* imgs) {
+  JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
   if (im.fused_gab_epf1 != 2) return;
   const int w = im.w, h = im.h, wp = im.wp;

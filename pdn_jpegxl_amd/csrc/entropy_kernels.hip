@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds, bool kGeneric = true>
-__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int scalar_rows) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int slots, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const 
 
 // ------------------------------------------------------------------ LF groups, phase B: one workgroup (4 wavefronts) per LF group
 // Predictors of the row-static channels, then the chroma-from-luma / sharpness maps and the varblock placement.
-__global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, const SectionTask* tasks) {
+__global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks) {
   __shared__ int32_t s_carry[4][256];
   __shared__ uint32_t s_count, s_flag;
   __shared__ uint32_t s_part[256];
@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(256) void lf_finish_kernel(const DevImage* imgs, co
 // context of its three channels, so that the serial token loop below never waits on cellinfo / raw-quant / context-map
 // loads: it streams 8-byte descriptors, fetched one block ahead.
 //   one word: bx | by << 5 | log2cx << 10 | log2cy << 13 | block context of Y << 16 | X << 21 | B << 26   (at most 16 block contexts)
-__global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   const int g = blockIdx.x;
   if (g >= im.ng || im.is_modular) return;
@@ -1432,7 +1432,7 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* imgs) 
 // what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
 // (the task's section count rounded up to four: every workgroup uses what ITS image's tables leave of the launch's LDS).
 template <bool kLds, int kRing>
-__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
+__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lane_stride) {
   JXL_SERIAL_PRIO();
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
@@ -1754,7 +1754,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, co
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds, bool kGeneric = true>
-__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
+__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1800,7 +1800,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
 }
 
 // Phase B: one wavefront per group: predictors (or plain conversion) -> 8-bit alpha plane.
-__global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* __restrict__ imgs) {
   __shared__ int32_t s_carry[256];
   __shared__ int32_t s_tile[64 * 65];
   const DevImage& im = imgs[blockIdx.y];
@@ -1880,7 +1880,7 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // row-static loops already keep their chains on the scalar unit - so that per-sample channels can use the lanes (modular_uniform.h).
 // LDS of that shape: bit windows | 3 rows | weighted-predictor rows | grid | tree + code.
 template <bool kLds, bool kUni = false>
-__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1964,7 +1964,7 @@ __global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, c
 }
 
 // Phase B: one wavefront per (section, coded channel)
-__global__ __launch_bounds__(64) void modular_finish_kernel(const DevImage* imgs, int max_coded) {
+__global__ __launch_bounds__(64) void modular_finish_kernel(const DevImage* __restrict__ imgs, int max_coded) {
   __shared__ int32_t s_carry[kCarryInts];
   __shared__ int32_t s_tile[64 * 65];
   const DevImage& im = imgs[blockIdx.y];
@@ -2055,7 +2055,7 @@ __global__ void rct_inverse_kernel(int32_t* p0, int32_t* p1, int32_t* p2, size_t
 
 // Inverse reversible colour transforms (last first), clamp, interleave.  CMYK streams (black extra channel): C, M, Y, K leave as
 // 255 - stored sample (Decoder/JxlDecoder.cpp:159-215: the stream stores 0 = full ink, the host wants 0 = no ink), alpha as it is.
-__global__ void modular_out_kernel(const DevImage* imgs) {
+__global__ void modular_out_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   if (!im.is_modular) return;
   const size_t n = (size_t)im.w * im.h;

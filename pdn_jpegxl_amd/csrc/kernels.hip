@@ -19,7 +19,7 @@ __device__ __forceinline__ int DMirror(int v, int n) {
 }
 
 // ------------------------------------------------------------------ LF pixel stages
-__global__ void lf_dequant_kernel(const DevImage* imgs) {
+__global__ void lf_dequant_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   const int n = im.w8 * im.h8;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -34,7 +34,7 @@ __global__ void lf_dequant_kernel(const DevImage* imgs) {
   }
 }
 
-__global__ void lf_smooth_kernel(const DevImage* imgs) {
+__global__ void lf_smooth_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   if (im.skip_lf_smoothing) return;
   const int w = im.w8, h = im.h8, n = w * h;
@@ -59,7 +59,7 @@ __global__ void lf_smooth_kernel(const DevImage* imgs) {
   }
 }
 
-__global__ void cell_sigma_kernel(const DevImage* imgs) {
+__global__ void cell_sigma_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   const int n = im.w8 * im.h8;
   const float kInvSigmaNum = -1.1715728752538099024f;
@@ -89,7 +89,7 @@ __global__ void cell_sigma_kernel(const DevImage* imgs) {
 // Dense int32 coefficient planes (footprint layout: coefficient (ky, kx) of a varblock at pixel (y0 + ky, x0 + kx)) for the tiles the
 // generic kernels handle, from the sparse entry lists hf_decode_kernel wrote: first zeros, then (a second launch: a varblock
 // larger than a tile reaches into other listed tiles) every entry of the varblocks that START in the tile.
-__global__ void expand_zero_kernel(const DevImage* imgs, int all) {
+__global__ void expand_zero_kernel(const DevImage* __restrict__ imgs, int all) {
   const DevImage& im = imgs[blockIdx.y];
   if (im.is_modular) return;
   FOR_TILES(im, tile, all) {
@@ -103,7 +103,7 @@ __global__ void expand_zero_kernel(const DevImage* imgs, int all) {
     }
   }
 }
-__global__ void expand_scatter_kernel(const DevImage* imgs, int all) {
+__global__ void expand_scatter_kernel(const DevImage* __restrict__ imgs, int all) {
   const DevImage& im = imgs[blockIdx.y];
   if (im.is_modular) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;
@@ -147,7 +147,7 @@ __global__ void expand_scatter_kernel(const DevImage* imgs, int all) {
   }
 }
 
-__global__ void dequant_kernel(const DevImage* imgs) {
+__global__ void dequant_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
@@ -197,7 +197,7 @@ __global__ void dequant_kernel(const DevImage* imgs) {
 }
 
 // LLF: the lowest cx*cy coefficients of each varblock from the (smoothed) LF image; one thread per cell.
-__global__ void llf_kernel(const DevImage* imgs, const float* basis_small, const float* llf_scale) {
+__global__ void llf_kernel(const DevImage* __restrict__ imgs, const float* basis_small, const float* llf_scale) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
@@ -240,7 +240,7 @@ __device__ __forceinline__ bool GemmTile(const DevImage& im, int tx, int ty) {
 // LDS (one of them is a slice of the basis, the other a slice of the coefficient / intermediate plane); wavefront w owns output
 // rows 16 w .. 16 w + 15, four 16 x 16 accumulators.  pass 0: tmp = Basis_R^T * coefficients (columns); pass 1: xyb = tmp * Basis_C.
 typedef float __attribute__((ext_vector_type(4))) GF4;
-__global__ __launch_bounds__(256) void idct_gemm_kernel(const DevImage* imgs, const float* basis_all, int pass) {
+__global__ __launch_bounds__(256) void idct_gemm_kernel(const DevImage* __restrict__ imgs, const float* basis_all, int pass) {
   __shared__ float s_a[64 * 17];   // A[m][k], pitch 17
   __shared__ float s_b[16 * 65];   // B[k][n], pitch 65
   const DevImage& im = imgs[blockIdx.y];
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256) void idct_gemm_kernel(const DevImage* imgs, co
 }
 
 // Vertical 1-D IDCT: thread = (column x, 8-row cell), all three channels.
-__global__ void idct_v_kernel(const DevImage* imgs, const float* basis_all) {
+__global__ void idct_v_kernel(const DevImage* __restrict__ imgs, const float* basis_all) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
@@ -334,7 +334,7 @@ __global__ void idct_v_kernel(const DevImage* imgs, const float* basis_all) {
 }
 
 // Horizontal 1-D IDCT: thread = (row y, 8-column cell).
-__global__ void idct_h_kernel(const DevImage* imgs, const float* basis_all) {
+__global__ void idct_h_kernel(const DevImage* __restrict__ imgs, const float* basis_all) {
   const DevImage& im = imgs[blockIdx.y];
   FOR_LISTED_TILES(im, tile) {
     const int tx = tile % im.wt, ty = tile / im.wt;
@@ -377,7 +377,7 @@ __device__ __forceinline__ void Idct1(const float* B, int n, const float* in, in
 }
 
 // 8x8 special transforms: IDENTITY, DCT2X2, DCT4X4, DCT4X8, DCT8X4.  One thread per (cell, channel).
-__global__ void idct_special_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small) {
+__global__ void idct_special_kernel(const DevImage* __restrict__ imgs, const float* basis_all, const float* basis_small) {
   const DevImage& im = imgs[blockIdx.y];
   const float* B8 = basis_all;                 // N = 8
   const float* B4 = basis_small + (16 - 1) / 3;  // c = 4

@@ -244,7 +244,7 @@ constexpr int kTileF = kTS * kLP;   // floats of one channel's tile
 //   * the per-cell set-up (cell info, scale, table pointers, entry-list prefixes of the three channels) is done once per tile by
 //     wavefront 0; LLF of channel t is computed by the first wavefront of team t with lane shuffles while the others scatter.
 //   * 1 / v through v_rcp_f32 (1 ulp; the term is a bias correction <= 0.15 / |v|).
-__global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs, const float* basis_all, const float* basis_small,
+__global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __restrict__ imgs, const float* basis_all, const float* basis_small,
                                                              const float* llf_scale, const float* basis_mfma) {
   JXL_PIXEL_PRIO();
   extern __shared__ __align__(16) uint8_t smem_raw[];
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* imgs
 // ------------------------------------------------------------------ LDS-tiled loop filters
 // kStage: 0 Gaborish, 1 EPF pass 0, 2 EPF pass 1, 3 EPF pass 2.  Tile = 64 x 32 output pixels.
 template <int kStage>
-__global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(256) void filter_tile_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   constexpr int TW = 64, TH = 32;
   constexpr int HALO = kStage == 0 ? 1 : (kStage == 1 ? 3 : (kStage == 2 ? 2 : 1));
@@ -795,7 +795,7 @@ __device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst&
   st.hd[s1] = hd2;   // of dv[r-3]: next row's hd1
 }
 
-__global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
   if (!im.fused_gab_epf1) return;
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* i
 // (a wavefront = 256 columns, the outer quads are halo), same output paths.  With it a two-iteration frame runs
 // reconstruction -> two streaming kernels instead of three LDS-tiled stage kernels (measured, 384 4K frames at distance 2:
 // filters + output 104.8 ms before).
-__global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* imgs) {
+__global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
   if (im.fused_gab_epf1 != 2) return;
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* img
 }
 
 // no loop filter at all: plain conversion
-__global__ void out_only_kernel(const DevImage* imgs) {
+__global__ void out_only_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
   if (im.final_stage != 4) return;
   const int w = im.w, wp = im.wp;

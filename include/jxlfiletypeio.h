@@ -171,7 +171,8 @@ JXLFILETYPEIO_API size_t jxlhip_read_plane(JxlHipDecoder* dec, int32_t index, co
  * 64 = one section per wavefront ... 1 = one section per lane), "overlap" (0/1: run the LF stage of the next
  * asynchronous batch on a second stream while the previous batch finishes), "band_first_row" / "band_rows" (>= 0: decode only these
  * 256-pixel group rows of a lossy frame into a band-sized buffer), "no_direct" / "mod_lanes64" (launch shapes of the vector loops for
- * small launches as well; same output).  Returns 1 if the option exists and the value is valid (0: refused, nothing changed). */
+ * small launches as well; same output), "no_stream_pairs" (every fused Gaborish + EPF frame through the four-pixels-per-lane kernel;
+ * same output).  Returns 1 if the option exists and the value is valid (0: refused, nothing changed). */
 JXLFILETYPEIO_API int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value);
 
 /* Timing of the last synchronised batch: milliseconds per named stage (HIP events on the decode stream). */

@@ -172,6 +172,7 @@ struct JxlHipDecoder {
   bool debug_taps = false;
   // band-restricted decode (multi-GPU sharding of one frame by group rows): 0 rows = whole frame
   int band_first_row = 0, band_rows = 0;
+  bool no_stream_pairs = false;   // every fused frame through the four-pixels-per-lane filter kernel (parity tests: same output either way)
   bool no_direct = false, mod_lanes64 = false;   // launch shapes of the vector loops for small launches too (parity tests: same output either way)
   bool overlap = true;
 
@@ -662,17 +663,17 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   // width) plus 288 B per lane, and a launch has ONE LDS size.  Sized by the batch-wide maximum, a single image with wide tables
   // pushed every workgroup from two per CU to one (hf_decode 30 -> 58 ms at batch 384); instead every image gets as many lanes per
   // workgroup as fit beside ITS tables in the budget (whole wavefronts; images with wide tables use more, smaller workgroups).
-  // The budget: LDS is what the three pipelined chains compete for (profiles/r03_experiment_cu_masks.txt: confined to N CUs the
-  // HF kernel takes 12 700 CU-ms / N, it is bound by resident workgroups, not by latency).  With 80 KB a 4K frame (135 sections,
-  // ~50 KB of tables) needed two workgroups of 77 KB, each with its own copy of the tables; 112 KB holds the frame in one of 96 KB and
-  // leaves room for one reconstruction workgroup beside it: step 123 -> 115 ms (profiles/r03_experiment_hf_lds_budget.txt).
+  // The budget (half a CU's LDS) was re-measured in round 3 against 96 / 112 / 128 KB (one workgroup per 4K frame, one copy of its
+  // tables): those won 6 % of the pipelined step while the fused filter kernel held 252 registers, and nothing since it holds 122
+  // (profiles/r03_experiment_hf_lds_budget.txt, r03_experiment_pairs_balance.txt); alone, the HF kernel is 36 ms with 80 KB and 65 ms
+  // with 112 KB (two rounds of workgroups), so 80 KB it stays.
   auto hf_code_bytes = [](const HostCode& c) { return 8 + 8 * c.alias.size() + 4 * c.cfg.size() + c.ctx_map.size() + 64 + 32; };
   auto hf_table_bytes = [&](const ParsedFrame& f) {   // the widest of the frame's passes
     size_t b = hf_code_bytes(f.acode);
     for (auto& ep : f.extra_passes) b = std::max(b, hf_code_bytes(ep.acode));
     return b;
   };
-  size_t kHfLdsTarget = 112 * 1024;
+  size_t kHfLdsTarget = 80 * 1024;
   if (const char* e = Knob("JXLHIP_HF_LDS_KB")) { const int kb = atoi(e); if (kb >= 32 && kb <= 160) kHfLdsTarget = (size_t)kb * 1024; }   // experiment knob
   auto hf_per_wg = [&](const ParsedFrame& f) {
     // the fewest workgroups whose (tables + lanes) fit the budget, the image's sections spread evenly over them: every workgroup
@@ -747,7 +748,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
-  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused = false, any_fused2 = false;
+  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused2 = false;
+  int any_fused = 0;   // 1: fused frames of the two-pixels-per-lane kernel, 2: others
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
@@ -1023,7 +1025,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // the common configuration (Gaborish + one EPF iteration) runs as ONE kernel: the Gaborish result never leaves LDS
     // ... and two iterations as two streaming kernels (the first one's rows go through the f32 planes of stage_out[0])
     d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : ((!debug_taps && f.gab && f.epf_iters == 2) ? 2 : 0);
-    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5; any_fused = true; any_fused2 |= d.fused_gab_epf1 == 2; }
+    // the layouts filter_stream_pairs_kernel handles: even width, and RGBA8 output with the alpha plane or the f32 rows of a first iteration
+    d.stream_pairs = (d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs &&
+                      (d.fused_gab_epf1 == 2 || (d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply && d.nch_out == 4 && d.has_alpha))) ? 1 : 0;
+    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5; any_fused |= d.stream_pairs ? 1 : 2; any_fused2 |= d.fused_gab_epf1 == 2; }
     any_unfiltered |= d.final_stage == 4;
     max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
     max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));
@@ -1167,8 +1172,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   if (!(skip_stages & 2))
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, lds_hf_lanes, s_hf);
   Mark("hf_decode", s_hf, 1);
-  // alpha follows the HF tokens in every pass-group section: same (latency-bound) chain, so that the main stream carries
-  // nothing but the bandwidth-bound pixel stages
+  // alpha follows the HF tokens in every pass-group section (its first bit is where the HF kernel stopped reading): same chain,
+  // necessarily; the main stream carries nothing but the pixel stages
   if (any_alpha && !(skip_stages & 4))
     LaunchAlphaAns(d_imgs, (const SectionTask*)(d_blob + off_alpha_tasks), nalpha_t, alpha_stride, lds_alpha <= kLdsMax ? lds_alpha : 0, direct_alpha, lean_mod, s_hf);
   Mark("alpha_ans", s_hf, 1);
@@ -1178,13 +1183,22 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamSynchronize(stream));
     CopyPlaneTap(0);
   }
-  if (any_alpha && !(skip_stages & 4)) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
-  Mark("alpha_finish", s_hf, 1);
+  // the alpha planes' prediction pass: on the pixel stream of ITS batch rather than behind the token pass on the HF stream, which is
+  // the longest of the three chains (knob JXLHIP_ALPHA_FINISH_ON_HF: the old placement)
+  const bool finish_on_hf = s_hf == stream || debug_taps || Knob("JXLHIP_ALPHA_FINISH_ON_HF");
+  if (finish_on_hf) {
+    if (any_alpha && !(skip_stages & 4)) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
+    Mark("alpha_finish", s_hf, 1);
+  }
   if (s_hf != stream) {
     HIP_OK(hipEventRecord(S.hf_done, s_hf));
     HIP_OK(hipStreamWaitEvent(stream, S.hf_done, 0));
   }
   Mark("main_start", stream, 2);
+  if (!finish_on_hf) {
+    if (any_alpha && !(skip_stages & 4)) LaunchAlphaFinish(d_imgs, n, max_groups, stream);
+    Mark("alpha_finish", stream, 2);
+  }
   // experiment knob: the pixel stages behind the HF chain on ITS stream (no overlap between a batch's pixels and the next batch's HF decode)
   hipStream_t s_pix = (Knob("JXLHIP_PIX_ON_HF") && s_hf != stream) ? s_hf : stream;
   for (int c0 = 0; c0 < n; c0 += pixel_chunk) {
@@ -1485,6 +1499,7 @@ int32_t jxlhip_set_option(JxlHipDecoder* dec, const char* name, int32_t value) {
   if (!strcmp(name, "band_first_row")) { if (value < 0) return 0; dec->band_first_row = value; return 1; }
   if (!strcmp(name, "band_rows")) { if (value < 0) return 0; dec->band_rows = value; return 1; }
   if (!strcmp(name, "no_direct")) { dec->no_direct = value != 0; return 1; }
+  if (!strcmp(name, "no_stream_pairs")) { dec->no_stream_pairs = value != 0; return 1; }
   if (!strcmp(name, "mod_lanes64")) { dec->mod_lanes64 = value != 0; return 1; }
   if (!strcmp(name, "overlap")) { dec->overlap = value != 0; return 1; }
   return 0;

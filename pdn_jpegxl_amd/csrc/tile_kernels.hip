@@ -798,7 +798,7 @@ __device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst&
 __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
-  if (!im.fused_gab_epf1) return;
+  if (!im.fused_gab_epf1 || im.stream_pairs) return;   // (the common layouts run in filter_stream_pairs_kernel)
   StreamConst k;
   k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8;
   const int strips = (k.w + kStripOut - 1) / kStripOut;
@@ -851,6 +851,188 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* _
     StreamRow<1>(im, k, st, next, r + 1);
     StreamRow<2>(im, k, st, next, r + 2);
     StreamRow<3>(im, k, st, next, r + 3);
+  }
+}
+
+// ---- The same kernel for the common layouts, TWO pixels per lane --------------------------------------------------------------------
+// (even width >= 8; RGBA8 output with an alpha plane, or the f32 rows of a first of two iterations.)  What it changes, and why:
+//  * half the window state per lane -> 128 registers instead of 252: four wavefronts per SIMD instead of two, and a wavefront of
+//    this kernel still fits on a SIMD that an entropy wavefront of another batch occupies (measured in the pipelined step: with 252
+//    registers ONE wavefront fitted beside an entropy wavefront, the kernel ran at half speed whenever the chains overlapped);
+//  * buffer addressing (a 128-bit resource in scalar registers + a scalar row offset + the lane's 32-bit byte offset): no per-lane
+//    64-bit addresses to compute or keep;
+//  * no load sits in a branch: the pair left of column 0 and the pairs right of column w - 1 are pairs inside the frame, mirrored -
+//    such a lane loads the pair it mirrors and swaps it.  (With loads in divergent branches the compiler loses count of the loads in
+//    flight at the join and waits for ALL of them, the prefetched row included);
+//  * the sigma cell and the alpha pair of a row are requested one row ahead, like the input pairs.
+// A strip = 128 columns, the outer two pairs each side are halo (the filters reach 3 columns): 120 output columns.
+typedef float __attribute__((ext_vector_type(2))) F2;
+typedef unsigned __attribute__((ext_vector_type(2))) U2v;
+constexpr int kPairOut = 2 * (kStripLanes - 4);
+__device__ __forceinline__ F2 ShiftFromLeft(F2 v) { return F2{DppFromLeft(v.y), v.x}; }
+__device__ __forceinline__ F2 ShiftFromRight(F2 v) { return F2{v.y, DppFromRight(v.x)}; }
+__device__ __forceinline__ F2 ShiftFromLeft2(F2 v) { return F2{DppFromLeft(v.x), DppFromLeft(v.y)}; }
+__device__ __forceinline__ F2 Abs2(F2 v) { return F2{fabsf(v.x), fabsf(v.y)}; }
+struct PairRow { F2 c[3]; };
+struct PairState {
+  PairRow in[4], s[4], g[4];
+  F2 dv[4], dh[4], hd[4];
+};
+struct PairConst {
+  __amdgpu_buffer_rsrc_t in0, in1, in2, sigma, alpha, out, f0, f1, f2;
+  float gw0[3], gw1[3], gw2[3], cs[3], bsm;
+  int w, h, wp, w8, y0, y1, r_end, band_y0;
+  uint32_t in_bytes, cell_bytes, alpha_bytes, out_bytes;   // the lane's byte offsets inside a row: mirrored input pair, sigma cell, alpha pair, pair
+  bool outside, stores, to_float, use_alpha, xb_lo, xb_hi;
+};
+struct PairAux { float is; uint32_t al; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t PlaneResource(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7FFFFFFF, 0x00020000);   // raw buffer, no swizzle; the planes are smaller than 2 GB
+}
+__device__ __forceinline__ PairRow LoadPairRow(const PairConst& k, int y) {
+  const int yy = y < 0 ? -y - 1 : (y >= k.h ? 2 * k.h - 1 - y : y);   // uniform over the wavefront
+  const uint32_t row = (uint32_t)yy * (uint32_t)k.wp * 4u;
+  PairRow r;
+  r.c[0] = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(k.in0, k.in_bytes, row, 0));
+  r.c[1] = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(k.in1, k.in_bytes, row, 0));
+  r.c[2] = __builtin_bit_cast(F2, __builtin_amdgcn_raw_buffer_load_b64(k.in2, k.in_bytes, row, 0));
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const F2 v = r.c[c];
+    r.c[c] = k.outside ? F2{v.y, v.x} : v;
+  }
+  return r;
+}
+__device__ __forceinline__ PairAux LoadPairAux(const PairConst& k, int y) {
+  const int yc = min(max(y, 0), k.h - 1);
+  PairAux a;
+  a.is = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(k.sigma, k.cell_bytes, (uint32_t)(yc >> 3) * (uint32_t)k.w8 * 4u, 0));
+  a.al = (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(k.alpha, k.alpha_bytes, (uint32_t)yc * (uint32_t)k.w, 0);
+  return a;
+}
+template <int P>
+__device__ __forceinline__ void PairStreamRow(const DevImage& im, const PairConst& k, PairState& st, PairRow& next, PairAux& next_aux, int r) {
+  constexpr int s0 = P, s1 = (P + 1) & 3, s2 = (P + 2) & 3, s3 = (P + 3) & 3;   // slots of rows r (= r - 4), r - 3, r - 2, r - 1
+  const PairRow cur = next;
+  const PairAux aux = next_aux;
+  // all the next row reads from memory, a whole row of arithmetic ahead of its use
+  next = LoadPairRow(k, min(r + 1, k.r_end - 1));
+  next_aux = LoadPairAux(k, r - 2);
+  const int y = r - 3;   // the output row
+  const float is = aux.is;
+  const uint32_t al = k.use_alpha ? aux.al : 0xFFFFu;
+  const F2 zero = {0.f, 0.f};
+  F2 dhn = zero, dvn = zero;
+  st.in[s0] = cur;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    st.s[s0].c[c] = ShiftFromLeft(cur.c[c]) + ShiftFromRight(cur.c[c]);
+    const F2 gn = st.in[s3].c[c] * k.gw0[c] + ((st.in[s2].c[c] + cur.c[c]) + st.s[s3].c[c]) * k.gw1[c] + (st.s[s2].c[c] + st.s[s0].c[c]) * k.gw2[c];
+    dhn += Abs2(gn - ShiftFromRight(gn)) * k.cs[c];
+    dvn += Abs2(st.g[s2].c[c] - gn) * k.cs[c];
+    st.g[s3].c[c] = gn;
+  }
+  const F2 dv0 = st.dv[s3], dv1 = st.dv[s0], dv2 = st.dv[s1];
+  const F2 hd2 = ShiftFromLeft(dv2) + ShiftFromRight(dv2);
+  const F2 hd1 = st.hd[s0];
+  if (y >= k.y0 && y < k.y1) {   // uniform over the wavefront
+    const F2 dh0 = st.dh[s0], dh1 = st.dh[s1], dh2 = st.dh[s2];
+    const F2 a = dv1 + dv2;
+    const F2 sad_u = a + dv0 + hd1, sad_d = a + dvn + hd2;
+    const F2 vh = dh0 + dh1 + dh2;
+    const F2 sad_r = vh + (ShiftFromLeft(dh1) + ShiftFromRight(dh1));
+    const F2 sad_l = ShiftFromLeft(vh) + (ShiftFromLeft2(dh1) + dh1);
+    const bool yb = ((y & 7) == 0) || ((y & 7) == 7);
+    const float inv_in = is * (yb ? k.bsm : 1.0f), inv_b = is * k.bsm;
+    const F2 inv = {k.xb_lo ? inv_b : inv_in, k.xb_hi ? inv_b : inv_in};
+    const bool skip = is < -3.90524291751269967465540850526868f;
+    F2 wu, wl, wr, wd, iw;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      wu[j] = fmaxf(0.f, 1.0f + sad_u[j] * inv[j]); wl[j] = fmaxf(0.f, 1.0f + sad_l[j] * inv[j]);
+      wr[j] = fmaxf(0.f, 1.0f + sad_r[j] * inv[j]); wd[j] = fmaxf(0.f, 1.0f + sad_d[j] * inv[j]);
+      iw[j] = __builtin_amdgcn_rcpf(1.0f + wu[j] + wl[j] + wr[j] + wd[j]);
+    }
+    F2 o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const F2 g1 = st.g[s1].c[c];
+      const F2 f = (g1 + wu * st.g[s0].c[c] + wl * ShiftFromLeft(g1) + wr * ShiftFromRight(g1) + wd * st.g[s2].c[c]) * iw;
+      o[c] = skip ? g1 : f;
+    }
+    if (k.stores) {
+      if (k.to_float) {
+        const uint32_t row = (uint32_t)y * (uint32_t)k.wp * 4u;
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2v, o[0]), k.f0, k.out_bytes, row, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2v, o[1]), k.f1, k.out_bytes, row, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(U2v, o[2]), k.f2, k.out_bytes, row, 0);
+      } else {
+        U2v px;
+        px.x = PixelToRgba8(im, o[0].x, o[1].x, o[2].x, al & 0xFF);
+        px.y = PixelToRgba8(im, o[0].y, o[1].y, o[2].y, (al >> 8) & 0xFF);
+        __builtin_amdgcn_raw_buffer_store_b64(px, k.out, k.out_bytes, (uint32_t)(y - k.band_y0) * (uint32_t)k.w * 4u, 0);
+      }
+    }
+  }
+  st.dv[s2] = dvn;
+  st.dh[s3] = dhn;
+  st.hd[s1] = hd2;
+}
+
+__global__ __launch_bounds__(256, 4) void filter_stream_pairs_kernel(const DevImage* __restrict__ imgs) {
+  JXL_PIXEL_PRIO();
+  const DevImage& im = imgs[blockIdx.y];
+  if (!im.fused_gab_epf1 || !im.stream_pairs) return;
+  PairConst k;
+  k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8; k.band_y0 = im.band_y0;
+  const int strips = (k.w + kPairOut - 1) / kPairOut;
+  k.to_float = im.fused_gab_epf1 == 2;
+  const int band_lo = k.to_float ? max(0, im.band_y0 - 1) : im.band_y0, band_hi = k.to_float ? min(k.h, im.band_y1 + 1) : im.band_y1;
+  const int segs = (band_hi - band_lo + kSegRows - 1) / kSegRows;
+  if ((int)blockIdx.x * kGroupsPerWg >= strips * segs) return;
+  // (the wavefront's index, given to the compiler as the uniform value it is: rows, segment bounds and row offsets are scalar)
+  const int gidx = blockIdx.x * kGroupsPerWg + __builtin_amdgcn_readfirstlane(threadIdx.x / kStripLanes);
+  const bool task = gidx < strips * segs;
+  const int gi = task ? gidx : strips * segs - 1;   // (every lane stays in the loop: DPP reads neighbouring lanes)
+  const int strip = gi % strips, seg = gi / strips;
+  const int q = threadIdx.x & (kStripLanes - 1);
+  const int X = strip * kPairOut - 4 + 2 * q;       // first column of the lane's pair; strips start on multiples of 8
+  k.y0 = band_lo + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, band_hi);
+  k.r_end = k.y1 + 3;
+  k.outside = X < 0 || X >= k.w;
+  const int xm = X < 0 ? -X - 2 : (X >= k.w ? 2 * k.w - 2 - X : X);   // the pair this lane loads: itself, or the pair it mirrors
+  k.in_bytes = (uint32_t)min(max(xm, 0), k.w - 2) * 4u;
+  const int xc = min(max(X, 0), k.w - 2);
+  k.cell_bytes = (uint32_t)(xc >> 3) * 4u;
+  k.alpha_bytes = (uint32_t)xc;
+  k.out_bytes = (uint32_t)xc * 4u;
+  k.stores = task && q >= 2 && q <= kStripLanes - 3 && X < k.w;
+  k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;   // component 0 is column 0 of a block / component 1 is column 7
+  k.use_alpha = im.has_alpha && !k.to_float;
+  k.in0 = PlaneResource(im.stage_in[0][0]); k.in1 = PlaneResource(im.stage_in[0][1]); k.in2 = PlaneResource(im.stage_in[0][2]);
+  k.sigma = PlaneResource(im.inv_sigma);
+  k.alpha = k.use_alpha ? PlaneResource(im.alpha) : k.in0;   // (ignored without alpha: any readable bytes)
+  k.out = PlaneResource(im.out);
+  k.f0 = PlaneResource(im.stage_out[0][0]); k.f1 = PlaneResource(im.stage_out[0][1]); k.f2 = PlaneResource(im.stage_out[0][2]);
+#pragma unroll
+  for (int c = 0; c < 3; c++) { k.gw0[c] = im.gab_w[c][0]; k.gw1[c] = im.gab_w[c][1]; k.gw2[c] = im.gab_w[c][2]; k.cs[c] = im.epf_channel_scale[c]; }
+  k.bsm = im.epf_border_sad_mul;
+  PairState st;
+  const F2 zero = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) { st.in[i].c[c] = zero; st.s[i].c[c] = zero; st.g[i].c[c] = zero; }
+    st.dv[i] = zero; st.dh[i] = zero; st.hd[i] = zero;
+  }
+  const int r0 = k.y0 - 3;
+  PairRow next = LoadPairRow(k, r0);
+  PairAux next_aux = LoadPairAux(k, r0 - 3);
+  for (int r = r0; r < k.r_end; r += 4) {   // four rows per trip, unconditionally (see filter_stream_kernel)
+    PairStreamRow<0>(im, k, st, next, next_aux, r);
+    PairStreamRow<1>(im, k, st, next, next_aux, r + 1);
+    PairStreamRow<2>(im, k, st, next, next_aux, r + 2);
+    PairStreamRow<3>(im, k, st, next, next_aux, r + 3);
   }
 }
 
@@ -974,13 +1156,15 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
-                       bool any_fused, bool any_fused2, hipStream_t s) {
+                       int any_fused, bool any_fused2, hipStream_t s) {   // any_fused: 1 = frames of the pair kernel, 2 = others
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
     // one wavefront per (strip, segment); + 2 rows: the first of two fused iterations also writes the rows its second one reads
     const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
-    hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
+    const int pair_groups = ((max_w + kPairOut - 1) / kPairOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
+    if (any_fused & 1) hipLaunchKernelGGL(filter_stream_pairs_kernel, dim3((pair_groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
+    if (any_fused & 2) hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
     if (any_fused2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);

@@ -384,6 +384,25 @@ def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle):
         assert np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("size", [(8, 8), (10, 40), (120, 131), (122, 20), (240, 9), (242, 140), (250, 300), (400, 259), (778, 531)])
+@pytest.mark.parametrize("distance", [1.0, 2.0])
+def test_filter_kernel_of_two_pixels_per_lane_matches_the_general_one(gpu_decoder, oracle, size, distance):
+    """RGBA8 frames of even width run Gaborish + the first EPF iteration in filter_stream_pairs_kernel (two pixels per lane, buffer
+    addressing, mirrored edge pairs loaded from inside the frame); every other layout runs filter_stream_kernel.  The same streams
+    through both must give identical bytes - widths around the 120-column strips, one and two EPF iterations - and match the oracle."""
+    w, h = size
+    img = synth(w, h, 31 + w)
+    data = oracle.encode(img, distance=distance)
+    pairs = gpu_decode(gpu_decoder, [data])[0]
+    try:
+        assert gpu_decoder.set_option("no_stream_pairs", 1)
+        general = gpu_decode(gpu_decoder, [data])[0]
+    finally:
+        gpu_decoder.set_option("no_stream_pairs", 0)
+    assert np.array_equal(pairs, general)
+    check_pixels(pairs, oracle.decode(data).pixels)
+
+
 @pytest.mark.parametrize("size", [(400, 300), (777, 531), (257, 300), (56, 64), (57, 9)])
 @pytest.mark.parametrize("layout", ["rgba", "rgb", "gray"])
 def test_two_epf_iterations_run_as_streaming_kernels(gpu_decoder, oracle, size, layout):

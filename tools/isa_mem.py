@@ -2,7 +2,7 @@
 import re, sys
 t = open(sys.argv[1]).read()
 m = re.search(r"^(\S*" + re.escape(sys.argv[2]) + r"\S*):\s*(;.*)?$", t, re.M)
-i = m.start(); j = t.index('s_endpgm', i)
+i = m.start(); j = t.index('.Lfunc_end', i)
 body = t[i:j].splitlines()
 lim = int(sys.argv[3]) if len(sys.argv) > 3 else 120
 print(m.group(1), len(body), 'lines')

@@ -748,8 +748,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
-  bool any_gab = false, any_alpha = false, any_unfiltered = false, any_fused2 = false;
-  int any_fused = 0;   // 1: fused frames of the two-pixels-per-lane kernel, 2: others
+  bool any_gab = false, any_alpha = false, any_unfiltered = false;
+  int any_fused = 0, any_fused2 = 0;   // 1: fused frames (with a second iteration) of the two-pixels-per-lane kernels, 2: others
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
   int max_epf = 0;
@@ -1025,10 +1025,18 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // the common configuration (Gaborish + one EPF iteration) runs as ONE kernel: the Gaborish result never leaves LDS
     // ... and two iterations as two streaming kernels (the first one's rows go through the f32 planes of stage_out[0])
     d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : ((!debug_taps && f.gab && f.epf_iters == 2) ? 2 : 0);
-    // the layouts filter_stream_pairs_kernel handles: even width, and RGBA8 output with the alpha plane or the f32 rows of a first iteration
-    d.stream_pairs = (d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs &&
-                      (d.fused_gab_epf1 == 2 || (d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply && d.nch_out == 4 && d.has_alpha))) ? 1 : 0;
-    if (d.fused_gab_epf1) { d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5; any_fused |= d.stream_pairs ? 1 : 2; any_fused2 |= d.fused_gab_epf1 == 2; }
+    // the layouts the two-pixels-per-lane kernels handle: even width; RGBA8 output with the alpha plane (bit 0: the Gaborish + first
+    // iteration kernel, which for a two-iteration frame writes f32 rows whatever the output; bit 1: the second iteration's kernel)
+    {
+      const bool even = d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs;
+      const bool rgba8 = d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply && d.nch_out == 4 && d.has_alpha;
+      d.stream_pairs = (even && (d.fused_gab_epf1 == 2 || rgba8) ? 1 : 0) | (even && d.fused_gab_epf1 == 2 && rgba8 ? 2 : 0);
+    }
+    if (d.fused_gab_epf1) {
+      d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5;
+      any_fused |= (d.stream_pairs & 1) ? 1 : 2;
+      if (d.fused_gab_epf1 == 2) any_fused2 |= (d.stream_pairs & 2) ? 1 : 2;
+    }
     any_unfiltered |= d.final_stage == 4;
     max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
     max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));

@@ -205,7 +205,7 @@ struct DevImage {
   int32_t final_stage;      // last enabled filter stage (0..3) converts to u8; 4 = no filter, out_only_kernel converts; 5 = fused kernel
   int32_t fused_gab_epf1;   // 1: Gaborish + one EPF iteration + output as one kernel (filter_stream_kernel); 2: two EPF iterations - that kernel
                             // leaves f32 rows in stage_out[0], filter_stream2_kernel does the second iteration and the output
-  int32_t stream_pairs;     // the fused kernel's two-pixels-per-lane form takes this frame (even width, RGBA8 + alpha or f32 rows)
+  int32_t stream_pairs;     // bit 0 / 1: the two-pixels-per-lane form of the fused kernel / of the second iteration's kernel takes this frame
   uint32_t* tile_list;      // 64x64 tiles left to the generic reconstruction kernels (count in status[1])
   uint8_t* alpha;           // w*h samples of the OUTPUT type (u8, or u16 when out_bits == 16), already scaled from alpha_bits
   uint8_t* out;             // w*h*nch_out interleaved samples of the output type

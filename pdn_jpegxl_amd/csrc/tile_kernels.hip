@@ -798,7 +798,7 @@ __device__ __forceinline__ void StreamRow(const DevImage& im, const StreamConst&
 __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
-  if (!im.fused_gab_epf1 || im.stream_pairs) return;   // (the common layouts run in filter_stream_pairs_kernel)
+  if (!im.fused_gab_epf1 || (im.stream_pairs & 1)) return;   // (the common layouts run in filter_stream_pairs_kernel)
   StreamConst k;
   k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8;
   const int strips = (k.w + kStripOut - 1) / kStripOut;
@@ -982,7 +982,7 @@ __device__ __forceinline__ void PairStreamRow(const DevImage& im, const PairCons
 __global__ __launch_bounds__(256, 4) void filter_stream_pairs_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
-  if (!im.fused_gab_epf1 || !im.stream_pairs) return;
+  if (!im.fused_gab_epf1 || !(im.stream_pairs & 1)) return;
   PairConst k;
   k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8; k.band_y0 = im.band_y0;
   const int strips = (k.w + kPairOut - 1) / kPairOut;
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256, 4) void filter_stream_pairs_kernel(const DevIm
 __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* __restrict__ imgs) {
   JXL_PIXEL_PRIO();
   const DevImage& im = imgs[blockIdx.y];
-  if (im.fused_gab_epf1 != 2) return;
+  if (im.fused_gab_epf1 != 2 || (im.stream_pairs & 2)) return;   // (RGBA8 frames of even width: filter_stream2_pairs_kernel)
   const int w = im.w, h = im.h, wp = im.wp;
   const int strips = (w + kStripOut - 1) / kStripOut;
   const int band_rows = im.band_y1 - im.band_y0;
@@ -1133,6 +1133,89 @@ __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* __r
   }
 }
 
+// The second iteration in the two-pixels-per-lane form (RGBA8 + alpha frames of even width): same addressing and edge handling as
+// filter_stream_pairs_kernel, one halo pair each side (the iteration reaches one column): 124 output columns per strip.
+constexpr int kPair2Out = 2 * (kStripLanes - 2);
+__global__ __launch_bounds__(256, 4) void filter_stream2_pairs_kernel(const DevImage* __restrict__ imgs) {
+  JXL_PIXEL_PRIO();
+  const DevImage& im = imgs[blockIdx.y];
+  if (im.fused_gab_epf1 != 2 || !(im.stream_pairs & 2)) return;
+  PairConst k;
+  k.w = im.w; k.h = im.h; k.wp = im.wp; k.w8 = im.w8; k.band_y0 = im.band_y0;
+  const int strips = (k.w + kPair2Out - 1) / kPair2Out;
+  const int segs = (im.band_y1 - im.band_y0 + kSegRows - 1) / kSegRows;
+  if ((int)blockIdx.x * kGroupsPerWg >= strips * segs) return;
+  const int gidx = blockIdx.x * kGroupsPerWg + __builtin_amdgcn_readfirstlane(threadIdx.x / kStripLanes);
+  const bool task = gidx < strips * segs;
+  const int gi = task ? gidx : strips * segs - 1;
+  const int strip = gi % strips, seg = gi / strips;
+  const int q = threadIdx.x & (kStripLanes - 1);
+  const int X = strip * kPair2Out - 2 + 2 * q;      // strips start on multiples of 4
+  k.y0 = im.band_y0 + seg * kSegRows; k.y1 = min(k.y0 + kSegRows, im.band_y1);
+  k.r_end = k.y1 + 1;                               // last input row + 1
+  k.outside = X < 0 || X >= k.w;
+  const int xm = X < 0 ? -X - 2 : (X >= k.w ? 2 * k.w - 2 - X : X);
+  k.in_bytes = (uint32_t)min(max(xm, 0), k.w - 2) * 4u;
+  const int xc = min(max(X, 0), k.w - 2);
+  k.cell_bytes = (uint32_t)(xc >> 3) * 4u;
+  k.alpha_bytes = (uint32_t)xc;
+  k.out_bytes = (uint32_t)xc * 4u;
+  k.stores = task && q >= 1 && q <= kStripLanes - 2 && X < k.w;
+  k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;
+  k.use_alpha = im.has_alpha != 0;
+  k.in0 = PlaneResource(im.stage_out[0][0]); k.in1 = PlaneResource(im.stage_out[0][1]); k.in2 = PlaneResource(im.stage_out[0][2]);
+  k.sigma = PlaneResource(im.inv_sigma);
+  k.alpha = k.use_alpha ? PlaneResource(im.alpha) : k.in0;
+  k.out = PlaneResource(im.out);
+  const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
+  const float sm = im.epf_pass2_sigma_scale, smb = sm * im.epf_border_sad_mul;
+  PairRow prev = LoadPairRow(k, k.y0 - 1);
+  PairRow cur = LoadPairRow(k, k.y0);
+  PairRow next = LoadPairRow(k, min(k.y0 + 1, k.r_end - 1));
+  PairAux aux = LoadPairAux(k, k.y0);
+  for (int y = k.y0; y < k.y1; y++) {
+    // two rows ahead for the pairs, one for sigma / alpha: nothing this row uses was requested in it
+    const PairRow next2 = LoadPairRow(k, min(y + 2, k.r_end - 1));
+    const PairAux aux2 = LoadPairAux(k, y + 1);
+    const float is = aux.is;
+    const uint32_t al = k.use_alpha ? aux.al : 0xFFFFu;
+    const F2 zero = {0.f, 0.f};
+    F2 su = zero, sd = zero, sl = zero, sr = zero;
+    F2 lft[3], rgt[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const float sc = c == 0 ? cs0 : (c == 1 ? cs1 : cs2);
+      lft[c] = ShiftFromLeft(cur.c[c]); rgt[c] = ShiftFromRight(cur.c[c]);
+      su += Abs2(cur.c[c] - prev.c[c]) * sc; sd += Abs2(cur.c[c] - next.c[c]) * sc;
+      sl += Abs2(cur.c[c] - lft[c]) * sc; sr += Abs2(cur.c[c] - rgt[c]) * sc;
+    }
+    const bool yb = ((y & 7) == 0) || ((y & 7) == 7);
+    const float inv_in = is * (yb ? smb : sm), inv_b = is * smb;
+    const F2 inv = {k.xb_lo ? inv_b : inv_in, k.xb_hi ? inv_b : inv_in};
+    const bool skip = is < -3.90524291751269967465540850526868f;
+    F2 wu, wl, wr, wd, iw;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      wu[j] = fmaxf(0.f, 1.0f + su[j] * inv[j]); wl[j] = fmaxf(0.f, 1.0f + sl[j] * inv[j]);
+      wr[j] = fmaxf(0.f, 1.0f + sr[j] * inv[j]); wd[j] = fmaxf(0.f, 1.0f + sd[j] * inv[j]);
+      iw[j] = __builtin_amdgcn_rcpf(1.0f + wu[j] + wl[j] + wr[j] + wd[j]);
+    }
+    F2 o[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      const F2 f = (cur.c[c] + wu * prev.c[c] + wl * lft[c] + wr * rgt[c] + wd * next.c[c]) * iw;
+      o[c] = skip ? cur.c[c] : f;
+    }
+    if (k.stores) {
+      U2v px;
+      px.x = PixelToRgba8(im, o[0].x, o[1].x, o[2].x, al & 0xFF);
+      px.y = PixelToRgba8(im, o[0].y, o[1].y, o[2].y, (al >> 8) & 0xFF);
+      __builtin_amdgcn_raw_buffer_store_b64(px, k.out, k.out_bytes, (uint32_t)(y - k.band_y0) * (uint32_t)k.w * 4u, 0);
+    }
+    prev = cur; cur = next; next = next2; aux = aux2;
+  }
+}
+
 // no loop filter at all: plain conversion
 __global__ void out_only_kernel(const DevImage* __restrict__ imgs) {
   const DevImage& im = imgs[blockIdx.y];
@@ -1156,7 +1239,7 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 }
 
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
-                       int any_fused, bool any_fused2, hipStream_t s) {   // any_fused: 1 = frames of the pair kernel, 2 = others
+                       int any_fused, int any_fused2, hipStream_t s) {   // any_fused / any_fused2: 1 = frames of the pair kernels, 2 = others
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
   if (any_fused) {
@@ -1165,7 +1248,9 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
     const int pair_groups = ((max_w + kPairOut - 1) / kPairOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
     if (any_fused & 1) hipLaunchKernelGGL(filter_stream_pairs_kernel, dim3((pair_groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
     if (any_fused & 2) hipLaunchKernelGGL(filter_stream_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
-    if (any_fused2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
+    const int pair2_groups = ((max_w + kPair2Out - 1) / kPair2Out) * ((max_h + kSegRows - 1) / kSegRows);
+    if (any_fused2 & 1) hipLaunchKernelGGL(filter_stream2_pairs_kernel, dim3((pair2_groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
+    if (any_fused2 & 2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
   }
   if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
   if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);

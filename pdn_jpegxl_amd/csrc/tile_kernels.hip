@@ -289,8 +289,11 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
       if (!(info >> 31)) bad = 1;
       else {
         const int ox = (tid & 7) - ix, oy = (tid >> 3) - iy;
-        // blocks larger than the tile, and the rare special 8x8 transforms, are left to the generic kernels
-        bad = ox < 0 || oy < 0 || ox + (1 << lcx) > 8 || oy + (1 << lcy) > 8 || Special(info & 0xFF);
+        // blocks larger than the tile, the rare special 8x8 transforms, and blocks that do not start on a multiple of their own size
+        // (every encoder aligns them, the format's placement rule does not; the matrix-core sub-blocks below rely on it) are left
+        // to the generic kernels
+        bad = ox < 0 || oy < 0 || ox + (1 << lcx) > 8 || oy + (1 << lcy) > 8 || Special(info & 0xFF) ||
+              (ox & ((1 << lcx) - 1)) != 0 || (oy & ((1 << lcy) - 1)) != 0;
       }
     }
     const bool valid = (info >> 31) && !bad;

@@ -748,11 +748,11 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
   for (auto& im : imgs) memset(&im, 0, sizeof(DevImage));
   status_off.assign(n, 0);
   size_t lds_hf = 0, lds_hf_lanes = 0, lds_lf = 0, lds_alpha = 0;   // lds_hf: tables + lanes, the largest workgroup; lds_hf_lanes: the most lanes (global-table variant)
-  bool any_gab = false, any_alpha = false, any_unfiltered = false;
+  bool any_alpha = false, any_unfiltered = false;
+  int stage_mask = 0;   // LDS-tiled loop-filter stage kernels some frame of the batch needs (bit s: filter_tile_kernel<s>)
   int any_fused = 0, any_fused2 = 0;   // 1: fused frames (with a second iteration) of the two-pixels-per-lane kernels, 2: others
   int max_w = 1, max_h = 1, max_tiles = 1;
   auto tiles_of = [](const ParsedFrame& f) { return (size_t)((f.w8 + 7) / 8) * ((f.h8 + 7) / 8); };
-  int max_epf = 0;
   size_t max_cells = 1, max_padded = 8;
   SectionTask* lf_tasks = (SectionTask*)(h_blob + off_lf_tasks);
   SectionTask* pass_tasks = (SectionTask*)(h_blob + off_pass_tasks);
@@ -1007,24 +1007,27 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     }
     if (f.tree_uses_wp) { d.wp_lf = (int32_t*)(wr + l.wp_lf); d.wp_grp = (int32_t*)(wr + l.wp_grp); d.wp_grp_ints = 10 * (kGroupDim + 2); }
     d.out = f.orientation == 1 ? dev_out[i] : wr + l.orient_tmp;
-    // stage routing (ping-pong between xyb and xyb2)
+    // Loop-filter routing.  Frames with EPF iterations run iteration 1 (+ Gaborish when no iteration 0 has to come between them) and
+    // iteration 2 in the streaming kernels: fused_gab_epf1 = 1: one kernel -> output; 2: two kernels, f32 rows (stream_mid) between
+    // them.  Three iterations (distance >= 4): Gaborish and iteration 0 first, as LDS-tiled stage kernels, then the two streaming
+    // kernels without Gaborish (stream_no_gab).  Stage kernels ping-pong between xyb and xyb2 (the dead dense-coefficient planes).
     float** cur = d.xyb;
     float** other = d.xyb2;
-    d.stage_on[0] = f.gab ? 1 : 0;
+    d.fused_gab_epf1 = (!debug_taps && f.epf_iters >= 1) ? (f.epf_iters == 1 ? 1 : 2) : 0;
+    d.stream_no_gab = (d.fused_gab_epf1 && (!f.gab || f.epf_iters == 3)) ? 1 : 0;
+    d.stage_on[0] = (f.gab && (!d.fused_gab_epf1 || f.epf_iters == 3)) ? 1 : 0;
     d.stage_on[1] = f.epf_iters == 3;
-    d.stage_on[2] = f.epf_iters >= 1;
-    d.stage_on[3] = f.epf_iters >= 2;
+    d.stage_on[2] = f.epf_iters >= 1 && !d.fused_gab_epf1;
+    d.stage_on[3] = f.epf_iters >= 2 && !d.fused_gab_epf1;
     d.stage_on[4] = 1;
     for (int s = 0; s < 5; s++) {
+      if (s == 2) for (int c = 0; c < 3; c++) { d.stream_in[c] = cur[c]; d.stream_mid[c] = other[c]; }
       for (int c = 0; c < 3; c++) { d.stage_in[s][c] = cur[c]; d.stage_out[s][c] = other[c]; }
       if (s < 4 && d.stage_on[s]) std::swap(cur, other);
     }
     d.final_stage = 4;
     for (int s = 0; s < 4; s++) if (d.stage_on[s]) d.final_stage = s;
     if (debug_taps) d.final_stage = 4;   // keep the filtered float planes for the stage taps; out_only_kernel converts
-    // the common configuration (Gaborish + one EPF iteration) runs as ONE kernel: the Gaborish result never leaves LDS
-    // ... and two iterations as two streaming kernels (the first one's rows go through the f32 planes of stage_out[0])
-    d.fused_gab_epf1 = (!debug_taps && f.gab && f.epf_iters == 1) ? 1 : ((!debug_taps && f.gab && f.epf_iters == 2) ? 2 : 0);
     // the layouts the two-pixels-per-lane kernels handle: even width; RGBA8 output with the alpha plane (bit 0: the Gaborish + first
     // iteration kernel, which for a two-iteration frame writes f32 rows whatever the output; bit 1: the second iteration's kernel)
     {
@@ -1033,16 +1036,15 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       d.stream_pairs = (even && (d.fused_gab_epf1 == 2 || rgba8) ? 1 : 0) | (even && d.fused_gab_epf1 == 2 && rgba8 ? 2 : 0);
     }
     if (d.fused_gab_epf1) {
-      d.stage_on[0] = d.stage_on[2] = d.stage_on[3] = 0; d.final_stage = 5;
+      d.final_stage = 5;
       any_fused |= (d.stream_pairs & 1) ? 1 : 2;
       if (d.fused_gab_epf1 == 2) any_fused2 |= (d.stream_pairs & 2) ? 1 : 2;
     }
     any_unfiltered |= d.final_stage == 4;
     max_w = std::max<int>(max_w, f.xsize); max_h = std::max<int>(max_h, f.ysize);
     max_tiles = std::max<int>(max_tiles, (int)tiles_of(f));
-    any_gab |= f.gab && !d.fused_gab_epf1;
+    for (int st = 0; st < 4; st++) if (d.stage_on[st]) stage_mask |= 1 << st;
     any_alpha |= d.has_alpha != 0;
-    if (!d.fused_gab_epf1) max_epf = std::max<int>(max_epf, f.epf_iters);
     max_cells = std::max(max_cells, (size_t)f.w8 * f.h8);
     max_padded = std::max(max_padded, (size_t)f.w8 * f.h8 * 64);
     // LDS budgets (must mirror the carving in entropy_kernels.hip)
@@ -1219,7 +1221,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     Mark("reconstruct_generic", s_pix, 2);
     if (debug_taps) { HIP_OK(hipStreamSynchronize(s_pix)); CopyPlaneTap(1); }
     if (!(skip_stages & 16))
-    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, any_gab, max_epf, any_unfiltered, any_fused, any_fused2, s_pix);
+    LaunchFilterTiles(d_imgs + c0, cnt, max_w, max_h, stage_mask, any_unfiltered, any_fused, any_fused2, s_pix);
     Mark("filters+output", s_pix, 2);
   }
   if (s_pix != stream) {

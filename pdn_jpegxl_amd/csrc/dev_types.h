@@ -205,6 +205,9 @@ struct DevImage {
   int32_t final_stage;      // last enabled filter stage (0..3) converts to u8; 4 = no filter, out_only_kernel converts; 5 = fused kernel
   int32_t fused_gab_epf1;   // 1: Gaborish + one EPF iteration + output as one kernel (filter_stream_kernel); 2: two EPF iterations - that kernel
                             // leaves f32 rows in stage_out[0], filter_stream2_kernel does the second iteration and the output
+  float* stream_in[3];      // input planes of the first streaming kernel (after the stage kernels that precede it, if any) ...
+  float* stream_mid[3];     // ... and the f32 rows between the two streaming kernels
+  int32_t stream_no_gab;    // the first streaming kernel skips Gaborish (frame without it, or done before iteration 0 by its stage kernel)
   int32_t stream_pairs;     // bit 0 / 1: the two-pixels-per-lane form of the fused kernel / of the second iteration's kernel takes this frame
   uint32_t* tile_list;      // 64x64 tiles left to the generic reconstruction kernels (count in status[1])
   uint8_t* alpha;           // w*h samples of the OUTPUT type (u8, or u16 when out_bits == 16), already scaled from alpha_bits

@@ -38,7 +38,7 @@ void LaunchGenericReconstruct(const DevImage* imgs, int nimg, const float* basis
 // tile_kernels.hip
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, const float* basis_mfma, hipStream_t s);
-void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
+void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, int stage_mask, bool any_unfiltered,
                        int any_fused, int any_fused2, hipStream_t s);
 
 }  // namespace jxlhip

@@ -823,15 +823,20 @@ __global__ __launch_bounds__(256, 2) void filter_stream_kernel(const DevImage* _
   k.interior = k.X >= 0 && k.X + 3 < k.w;
   k.stores = task && q >= 1 && q <= kStripLanes - 2 && k.X < k.w;
   k.full_quad = k.X + 3 < k.w;
-  k.in0 = (const JXL_GLOBAL float*)im.stage_in[0][0];
-  k.in1 = (const JXL_GLOBAL float*)im.stage_in[0][1];
-  k.in2 = (const JXL_GLOBAL float*)im.stage_in[0][2];
+  k.in0 = (const JXL_GLOBAL float*)im.stream_in[0];
+  k.in1 = (const JXL_GLOBAL float*)im.stream_in[1];
+  k.in2 = (const JXL_GLOBAL float*)im.stream_in[2];
+  const bool no_gab = im.stream_no_gab != 0;
   k.inv_sigma = (const JXL_GLOBAL float*)im.inv_sigma;
   k.alpha = (const JXL_GLOBAL uint8_t*)im.alpha;
   k.plain = PlainOutput(im);
-  k.f0 = (JXL_GLOBAL float*)im.stage_out[0][0]; k.f1 = (JXL_GLOBAL float*)im.stage_out[0][1]; k.f2 = (JXL_GLOBAL float*)im.stage_out[0][2];
+  k.f0 = (JXL_GLOBAL float*)im.stream_mid[0]; k.f1 = (JXL_GLOBAL float*)im.stream_mid[1]; k.f2 = (JXL_GLOBAL float*)im.stream_mid[2];
 #pragma unroll
-  for (int c = 0; c < 3; c++) { k.gw0[c] = im.gab_w[c][0]; k.gw1[c] = im.gab_w[c][1]; k.gw2[c] = im.gab_w[c][2]; k.cs[c] = im.epf_channel_scale[c]; }
+  for (int c = 0; c < 3; c++) {
+    // without Gaborish the kernel's weights are the identity: x * 1 + a * 0 + b * 0 is x exactly for finite planes
+    k.gw0[c] = no_gab ? 1.0f : im.gab_w[c][0]; k.gw1[c] = no_gab ? 0.0f : im.gab_w[c][1]; k.gw2[c] = no_gab ? 0.0f : im.gab_w[c][2];
+    k.cs[c] = im.epf_channel_scale[c];
+  }
   k.bsm = im.epf_border_sad_mul;
   // block-border columns of the quad: strips start on a multiple of 8, so X = 4 (q - 1) mod 8
   k.xb0 = (q & 1) != 0; k.xb3 = (q & 1) == 0;     // component 0 is column 0 of a block / component 3 is column 7
@@ -1012,13 +1017,18 @@ __global__ __launch_bounds__(256, 4) void filter_stream_pairs_kernel(const DevIm
   k.stores = task && q >= 2 && q <= kStripLanes - 3 && X < k.w;
   k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;   // component 0 is column 0 of a block / component 1 is column 7
   k.use_alpha = im.has_alpha && !k.to_float;
-  k.in0 = PlaneResource(im.stage_in[0][0]); k.in1 = PlaneResource(im.stage_in[0][1]); k.in2 = PlaneResource(im.stage_in[0][2]);
+  k.in0 = PlaneResource(im.stream_in[0]); k.in1 = PlaneResource(im.stream_in[1]); k.in2 = PlaneResource(im.stream_in[2]);
+  const bool no_gab = im.stream_no_gab != 0;
   k.sigma = PlaneResource(im.inv_sigma);
   k.alpha = k.use_alpha ? PlaneResource(im.alpha) : k.in0;   // (ignored without alpha: any readable bytes)
   k.out = PlaneResource(im.out);
-  k.f0 = PlaneResource(im.stage_out[0][0]); k.f1 = PlaneResource(im.stage_out[0][1]); k.f2 = PlaneResource(im.stage_out[0][2]);
+  k.f0 = PlaneResource(im.stream_mid[0]); k.f1 = PlaneResource(im.stream_mid[1]); k.f2 = PlaneResource(im.stream_mid[2]);
 #pragma unroll
-  for (int c = 0; c < 3; c++) { k.gw0[c] = im.gab_w[c][0]; k.gw1[c] = im.gab_w[c][1]; k.gw2[c] = im.gab_w[c][2]; k.cs[c] = im.epf_channel_scale[c]; }
+  for (int c = 0; c < 3; c++) {
+    // without Gaborish the kernel's weights are the identity: x * 1 + a * 0 + b * 0 is x exactly for finite planes
+    k.gw0[c] = no_gab ? 1.0f : im.gab_w[c][0]; k.gw1[c] = no_gab ? 0.0f : im.gab_w[c][1]; k.gw2[c] = no_gab ? 0.0f : im.gab_w[c][2];
+    k.cs[c] = im.epf_channel_scale[c];
+  }
   k.bsm = im.epf_border_sad_mul;
   PairState st;
   const F2 zero = {0.f, 0.f};
@@ -1063,9 +1073,9 @@ __global__ __launch_bounds__(256) void filter_stream2_kernel(const DevImage* __r
   const bool interior = X >= 0 && X + 3 < w;
   const bool stores = task && q >= 1 && q <= kStripLanes - 2 && X < w;
   const bool full_quad = X + 3 < w;
-  const JXL_GLOBAL float* in0 = (const JXL_GLOBAL float*)im.stage_out[0][0];
-  const JXL_GLOBAL float* in1 = (const JXL_GLOBAL float*)im.stage_out[0][1];
-  const JXL_GLOBAL float* in2 = (const JXL_GLOBAL float*)im.stage_out[0][2];
+  const JXL_GLOBAL float* in0 = (const JXL_GLOBAL float*)im.stream_mid[0];
+  const JXL_GLOBAL float* in1 = (const JXL_GLOBAL float*)im.stream_mid[1];
+  const JXL_GLOBAL float* in2 = (const JXL_GLOBAL float*)im.stream_mid[2];
   const JXL_GLOBAL float* inv_sigma = (const JXL_GLOBAL float*)im.inv_sigma;
   const bool plain = PlainOutput(im);
   const float cs0 = im.epf_channel_scale[0], cs1 = im.epf_channel_scale[1], cs2 = im.epf_channel_scale[2];
@@ -1166,7 +1176,7 @@ __global__ __launch_bounds__(256, 4) void filter_stream2_pairs_kernel(const DevI
   k.stores = task && q >= 1 && q <= kStripLanes - 2 && X < k.w;
   k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;
   k.use_alpha = im.has_alpha != 0;
-  k.in0 = PlaneResource(im.stage_out[0][0]); k.in1 = PlaneResource(im.stage_out[0][1]); k.in2 = PlaneResource(im.stage_out[0][2]);
+  k.in0 = PlaneResource(im.stream_mid[0]); k.in1 = PlaneResource(im.stream_mid[1]); k.in2 = PlaneResource(im.stream_mid[2]);
   k.sigma = PlaneResource(im.inv_sigma);
   k.alpha = k.use_alpha ? PlaneResource(im.alpha) : k.in0;
   k.out = PlaneResource(im.out);
@@ -1241,12 +1251,15 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
   hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale, basis_mfma);
 }
 
-void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, bool any_gab, int max_epf, bool any_unfiltered,
+void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, int stage_mask, bool any_unfiltered,
                        int any_fused, int any_fused2, hipStream_t s) {   // any_fused / any_fused2: 1 = frames of the pair kernels, 2 = others
   const int tiles = ((max_w + 63) / 64) * ((max_h + 31) / 32);
   dim3 g(tiles, nimg);
+  // Gaborish / iteration 0 as stage kernels: frames without EPF, frames with three iterations (before their streaming kernels), taps
+  if (stage_mask & 1) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
+  if (stage_mask & 2) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);
   if (any_fused) {
-    // one wavefront per (strip, segment); + 2 rows: the first of two fused iterations also writes the rows its second one reads
+    // one wavefront per (strip, segment); + 2 rows: the first of two streaming kernels also writes the rows its second one reads
     const int groups = ((max_w + kStripOut - 1) / kStripOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
     const int pair_groups = ((max_w + kPairOut - 1) / kPairOut) * ((max_h + 2 + kSegRows - 1) / kSegRows);
     if (any_fused & 1) hipLaunchKernelGGL(filter_stream_pairs_kernel, dim3((pair_groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
@@ -1255,10 +1268,8 @@ void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, boo
     if (any_fused2 & 1) hipLaunchKernelGGL(filter_stream2_pairs_kernel, dim3((pair2_groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
     if (any_fused2 & 2) hipLaunchKernelGGL(filter_stream2_kernel, dim3((groups + kGroupsPerWg - 1) / kGroupsPerWg, nimg), dim3(256), 0, s, imgs);
   }
-  if (any_gab) hipLaunchKernelGGL(filter_tile_kernel<0>, g, dim3(256), 0, s, imgs);
-  if (max_epf >= 3) hipLaunchKernelGGL(filter_tile_kernel<1>, g, dim3(256), 0, s, imgs);
-  if (max_epf >= 1) hipLaunchKernelGGL(filter_tile_kernel<2>, g, dim3(256), 0, s, imgs);
-  if (max_epf >= 2) hipLaunchKernelGGL(filter_tile_kernel<3>, g, dim3(256), 0, s, imgs);
+  if (stage_mask & 4) hipLaunchKernelGGL(filter_tile_kernel<2>, g, dim3(256), 0, s, imgs);   // (only with the stage taps)
+  if (stage_mask & 8) hipLaunchKernelGGL(filter_tile_kernel<3>, g, dim3(256), 0, s, imgs);
   if (any_unfiltered) {
     size_t work = (size_t)max_w * max_h;
     size_t b = std::min<size_t>((work + 255) / 256, 8192);

@@ -403,6 +403,30 @@ def test_filter_kernel_of_two_pixels_per_lane_matches_the_general_one(gpu_decode
     check_pixels(pairs, oracle.decode(data).pixels)
 
 
+@pytest.mark.parametrize("size", [(400, 300), (257, 301), (58, 70)])
+@pytest.mark.parametrize("gaborish,epf_iters", [(True, 3), (False, 3), (False, 1), (False, 2)])
+def test_streaming_kernels_without_gaborish_and_after_iteration_0(gpu_decoder, oracle, size, gaborish, epf_iters):
+    """Every frame with EPF iterations ends in the streaming kernels: frames without Gaborish run them with identity weights, frames with
+    three iterations run Gaborish and iteration 0 as stage kernels first.  Against the oracle, against the stage-by-stage decode of the
+    same stream (the taps switch the streaming kernels off), and both forms of the streaming kernels against each other."""
+    w, h = size
+    img = synth(w, h, 17 + epf_iters)
+    data = oracle.encode(img, distance=4.5 if epf_iters == 3 else 2.0, epf_iters=epf_iters, gaborish=gaborish)
+    ref = oracle.decode(data)
+    assert ref.epf_iters == epf_iters
+    streamed = gpu_decode(gpu_decoder, [data])[0]
+    check_pixels(streamed, ref.pixels)
+    staged = gpu_decode(gpu_decoder, [data], taps=True)[0]
+    d = np.abs(streamed.astype(np.int32) - staged.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3
+    try:
+        assert gpu_decoder.set_option("no_stream_pairs", 1)
+        general = gpu_decode(gpu_decoder, [data])[0]
+    finally:
+        gpu_decoder.set_option("no_stream_pairs", 0)
+    assert np.array_equal(streamed, general)
+
+
 @pytest.mark.parametrize("size", [(400, 300), (777, 531), (257, 300), (56, 64), (57, 9)])
 @pytest.mark.parametrize("layout", ["rgba", "rgb", "gray"])
 def test_two_epf_iterations_run_as_streaming_kernels(gpu_decoder, oracle, size, layout):

@@ -1105,7 +1105,7 @@ __device__ __forceinline__ void LoadModTables(const DevImage& im, uint8_t* smem,
 // (workgroup = one wavefront = up to 64 LF groups of ONE image, tables in LDS).  LF coefficients (3 channels) and the HF
 // metadata (chroma-from-luma maps, block info, sharpness) of the group are decoded into lfq / binfo scratch.
 template <bool kLds, bool kGeneric = true>
-__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int slots, int scalar_rows) {
+__global__ __launch_bounds__(64) void lf_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int slots, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1431,8 +1431,11 @@ __global__ __launch_bounds__(64) void hf_blocklist_kernel(const DevImage* __rest
 // faster loop for one frame; 16 (top-up every 8 tokens, 4 descriptors: 192 B per lane) lets more workgroups share a CU, which is
 // what matters when a batch launches more workgroups than the chip has CUs.  `nslots` = lanes the LDS arrays are laid out for
 // (the task's section count rounded up to four: every workgroup uses what ITS image's tables leave of the launch's LDS).
+// (the four serial decoders do NOT take the DevImage array as __restrict__ like the other kernels do: with it the compiler re-reads
+// frame fields through the scalar cache inside the token loops - 101 scalar loads instead of 24 in this kernel - and a lone section's
+// chain gets longer: hf_decode of one 4K frame 12.3 -> 12.8 ms)
 template <bool kLds, int kRing>
-__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lane_stride) {
+__global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride) {
   JXL_SERIAL_PRIO();
   constexpr int kTop = kRing / 2;   // tokens between top-ups: a token consumes at most 48 bits and starts at most one block ...
   constexpr int kQ = kRing / 4;     // ... so kTop tokens never outrun kRing - kRing / 4 + 1 words / kTop / 3 + 1 descriptors
@@ -1754,7 +1757,7 @@ __global__ __launch_bounds__(512) void hf_decode_kernel(const DevImage* __restri
 // ------------------------------------------------------------------ alpha (Modular stream after the HF tokens), phase A
 // One lane per pass-group section; a workgroup (one wavefront) holds sections of ONE image.
 template <bool kLds, bool kGeneric = true>
-__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
+__global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lane_stride, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];
@@ -1880,7 +1883,7 @@ __device__ __forceinline__ void ModSectionOf(const DevImage& im, int s, int* kin
 // row-static loops already keep their chains on the scalar unit - so that per-sample channels can use the lanes (modular_uniform.h).
 // LDS of that shape: bit windows | 3 rows | weighted-predictor rows | grid | tree + code.
 template <bool kLds, bool kUni = false>
-__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* __restrict__ imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
+__global__ __launch_bounds__(64) void modular_ans_kernel(const DevImage* imgs, const SectionTask* tasks, int lanes, int rb_width, int wp_lds, int scalar_rows) {
   JXL_SERIAL_PRIO();
   extern __shared__ __align__(16) uint8_t smem[];
   const SectionTask task = tasks[blockIdx.x];

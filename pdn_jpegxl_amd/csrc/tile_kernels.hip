@@ -72,6 +72,21 @@ __device__ __forceinline__ F4 MfmaChainT(const float* table, const float* po, in
     acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
   return acc;
 }
+// The 32-point table from an LDS copy (two arrays of 16-byte halves, so that consecutive (n, q) lanes read consecutive 16 bytes): the
+// global-memory table cost every 16x16 sub-block two dependent L2 round trips before its first MFMA.
+template <bool kTableIsA>
+__device__ __forceinline__ F4 MfmaChain32L(const float4* t_lo, const float4* t_hi, int pair, const float* po, int so) {
+  const float4 v0 = t_lo[pair], v1 = t_hi[pair];
+  const float t[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+  float o[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[k] = po[k * so];
+  F4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
+  return acc;
+}
 // offset of the N-point table inside basis_mfma (N = 32, 64), and of lane (n, q)'s run
 __device__ __forceinline__ const float* MfmaTable(const float* basis_mfma, int N, int n, int q) {
   return basis_mfma + (N == 32 ? 0 : 1024) + (n * 4 + q) * (N / 4);
@@ -258,6 +273,8 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
   uint32_t* cstart = cpre + 3 * 64;                    // 3 x 64   ... and where each origin cell's entries start in the group's list
   uint32_t* ctot = cstart + 3 * 64;                    // 4    totals per team
   const U32x2** csc = (const U32x2**)(ctot + 4);       // 64   scan list of the cell's quant table
+  float4* t32_lo = (float4*)(csc + 64);                // 128  k-contiguous 32-point basis, first / second four k-steps of lane (n, q) = [n * 4 + q]
+  float4* t32_hi = t32_lo + 128;                       // 128
   const DevImage& im = imgs[blockIdx.y];
   const int tile = blockIdx.x;
   if (tile >= im.wt * im.ht) return;
@@ -331,6 +348,10 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
     }
   } else if (tid < 64 + 320) {
     B816[tid - 64] = basis_all[tid - 64];   // basis_all holds N = 8 at offset 0 and N = 16 at offset 64
+  } else if (tid < 64 + 320 + 256) {
+    const int i = tid - (64 + 320);         // 16-byte piece i of the 32-point table: run (n, q) = i >> 1, half i & 1
+    const float4 v = ((const float4*)basis_mfma)[i];
+    if (i & 1) t32_hi[i >> 1] = v; else t32_lo[i >> 1] = v;
   }
   if (im.num_passes > 1) bad = 1;   // progressive frames: the passes' entries are summed as integers first (expand kernels, generic path)
   if (__syncthreads_or(bad)) {
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
         const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
         const float* cp = cfc + ((rb * 2 - iy) * 8 + lq) * kLP + x0 + l16;
         if (R == 16) acc[rb] = MfmaChain<16>(B816 + 64 + lq * 16 + iy * 8 + l16, 64, cp, 4 * kLP);
-        else if (R == 32) acc[rb] = MfmaChainT<32, true>(MfmaTable(basis_mfma, 32, iy * 8 + l16, lq), cp, 4 * kLP);
+        else if (R == 32) acc[rb] = MfmaChain32L<true>(t32_lo, t32_hi, (iy * 8 + l16) * 4 + lq, cp, 4 * kLP);
         else acc[rb] = MfmaChainT<64, true>(MfmaTable(basis_mfma, 64, iy * 8 + l16, lq), cp, 4 * kLP);
       }
     }
@@ -478,7 +499,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
         const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
         const float* ap = cfc + (y0 + l16) * kLP + (cs * 2 - ix) * 8 + lq;
         if (C == 16) acc[cs] = MfmaChain<16>(ap, 4, B816 + 64 + lq * 16 + ix * 8 + l16, 64);
-        else if (C == 32) acc[cs] = MfmaChainT<32, false>(MfmaTable(basis_mfma, 32, ix * 8 + l16, lq), ap, 4);
+        else if (C == 32) acc[cs] = MfmaChain32L<false>(t32_lo, t32_hi, (ix * 8 + l16) * 4 + lq, ap, 4);
         else acc[cs] = MfmaChainT<64, false>(MfmaTable(basis_mfma, 64, ix * 8 + l16, lq), ap, 4);
       }
     }
@@ -1245,7 +1266,7 @@ __global__ void out_only_kernel(const DevImage* __restrict__ imgs) {
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, const float* basis_mfma, hipStream_t s) {
   // three tiles, B816, four per-cell words + 2 x 3 prefix words per cell, totals, per-cell scan-list pointers
-  const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128) * 4;
+  const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128 + 1024) * 4;   // + the 32-point matrix-core table
   static bool raised = false;
   if (!raised) { (void)hipFuncSetAttribute((const void*)recon_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
   hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale, basis_mfma);

@@ -1803,7 +1803,7 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
 }
 
 // Phase B: one wavefront per group: predictors (or plain conversion) -> 8-bit alpha plane.
-__global__ __launch_bounds__(64) void alpha_finish_kernel(const DevImage* __restrict__ imgs) {
+__global__ __launch_bounds__(64, 3) void alpha_finish_kernel(const DevImage* __restrict__ imgs) {
   __shared__ int32_t s_carry[256];
   __shared__ int32_t s_tile[64 * 65];
   const DevImage& im = imgs[blockIdx.y];

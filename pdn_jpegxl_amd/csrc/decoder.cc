@@ -1178,6 +1178,21 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipEventRecord(S.lf_done, s_lf));
     HIP_OK(hipStreamWaitEvent(s_hf, S.lf_done, 0));
   }
+#ifdef JXLHIP_EXPERIMENTS
+  // JXLHIP_INTERFERE=kind,workgroups-per-CU,LDS-KB,ms: a probe kernel that occupies one resource (kernels.hip) starts with the HF stage on a
+  // stream of its own and runs for `ms`: which stage is sensitive to which resource (tools/interfere.sh)
+  if (const char* e = Knob("JXLHIP_INTERFERE")) {
+    int kind = 0, wgs = 1, lds_kb = 64; float ms = 100.f;
+    if (sscanf(e, "%d,%d,%d,%f", &kind, &wgs, &lds_kb, &ms) >= 1 && kind >= 1 && kind <= 6 && wgs >= 1 && wgs <= 16 && lds_kb >= 1 && lds_kb <= 160 && ms > 0 && ms < 2000) {
+      static hipStream_t xs = nullptr;
+      static float* xbuf = nullptr;
+      const size_t xbytes = (size_t)512 << 20;
+      if (!xs) { HIP_OK(hipStreamCreateWithFlags(&xs, hipStreamNonBlocking)); HIP_OK(hipMalloc(&xbuf, xbytes)); }
+      if (s_lf != s_hf) HIP_OK(hipStreamWaitEvent(xs, S.lf_done, 0));
+      LaunchInterference(kind, wgs, lds_kb, ms, xbuf, xbytes, xs);
+    }
+  }
+#endif
   Mark("hf_start", s_hf, 1);
   if (!(skip_stages & 2))
   LaunchHfDecode(d_imgs, (const SectionTask*)(d_blob + off_pass_tasks), npass_t, hf_waves * 64, lane_stride, hf_ring, lds_hf <= kLdsMax ? lds_hf : 0, lds_hf_lanes, s_hf);

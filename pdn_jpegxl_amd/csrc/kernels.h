@@ -41,4 +41,9 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, int stage_mask, bool any_unfiltered,
                        int any_fused, int any_fused2, hipStream_t s);
 
+#ifdef JXLHIP_EXPERIMENTS
+// occupies one kind of resource for `ms` milliseconds on stream s (kernels.hip, interference probes)
+void LaunchInterference(int kind, int wg_per_cu, int lds_kb, float ms, float* scratch, size_t scratch_bytes, hipStream_t s);
+#endif
+
 }  // namespace jxlhip

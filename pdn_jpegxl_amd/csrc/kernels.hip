@@ -514,4 +514,65 @@ void LaunchOrient(const uint8_t* src, uint8_t* dst, int w, int h, int px_bytes, 
   hipLaunchKernelGGL(orient_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, src, dst, w, h, px_bytes, orientation);
 }
 
+#ifdef JXLHIP_EXPERIMENTS
+// ------------------------------------------------------------------ interference probes (experiments build only)
+// A kernel that occupies ONE kind of resource for a given time while a decode stage runs beside it on another stream: which resource a
+// stage is sensitive to.  kind 1: dependent vector chain; 2: independent vector instructions (issue throughput); 3: LDS
+// traffic (read / write a 4 KB array); 4: LDS capacity (the launch's dynamic LDS, the wavefronts sleep); 5: registers (256 VGPRs per
+// wavefront, sleeping); 6: L2 / HBM traffic (streaming copy).  One wavefront per SIMD per workgroup.
+template <int kKind>
+__global__ __launch_bounds__(256) void interfere_kernel(float* sink, uint64_t ticks, const float4* src, float4* dst, size_t n4) {
+  extern __shared__ __align__(16) float lds[];
+  const uint64_t t0 = wall_clock64();
+  float a = (float)threadIdx.x, b = 1.0001f, c = 0.5f, d = 0.25f;
+  if (kKind == 3) for (int i = threadIdx.x; i < 1024; i += 256) lds[i] = (float)i;
+  if (kKind == 5) {
+    float r[250];   // kept alive across the sleep loop
+#pragma unroll
+    for (int i = 0; i < 250; i++) r[i] = a + (float)i;
+    while (wall_clock64() - t0 < ticks) {
+      __builtin_amdgcn_s_sleep(64);
+#pragma unroll
+      for (int i = 0; i < 250; i++) asm volatile("" : "+v"(r[i]));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 250; i++) sum += r[i];
+    if (sum == 12345.678f) sink[0] = sum;
+    return;
+  }
+  size_t pos = (size_t)blockIdx.x * 256 + threadIdx.x;
+  while (wall_clock64() - t0 < ticks) {
+    if (kKind == 1) {
+#pragma unroll
+      for (int i = 0; i < 64; i++) a = __builtin_fmaf(a, b, c);
+    } else if (kKind == 2) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) { a = __builtin_fmaf(a, b, c); b = __builtin_fmaf(b, 1.0f, 1e-9f); c = __builtin_fmaf(c, 0.999f, d); d = __builtin_fmaf(d, 1.0f, 1e-9f); }
+    } else if (kKind == 3) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) { const int j = (threadIdx.x * 17 + i * 64) & 1023; a += lds[j]; lds[(j + 256) & 1023] = a; }
+    } else if (kKind == 4) {
+      __builtin_amdgcn_s_sleep(64);
+    } else if (kKind == 6) {
+#pragma unroll
+      for (int i = 0; i < 4; i++) { dst[pos % n4] = src[pos % n4]; pos += (size_t)gridDim.x * 256; }
+    }
+  }
+  if (a + b + c + d == 12345.678f) sink[0] = a;
+}
+void LaunchInterference(int kind, int wg_per_cu, int lds_kb, float ms, float* scratch, size_t scratch_bytes, hipStream_t s) {
+  const uint64_t ticks = (uint64_t)(ms * 1e-3 * 100e6);   // wall_clock64 runs at 100 MHz
+  const dim3 g(256 * wg_per_cu), b(256);
+  const size_t lds = kind == 4 ? (size_t)lds_kb * 1024 : (kind == 3 ? 4096 : 0);
+  const size_t n4 = scratch_bytes / 32;
+  const float4* src = (const float4*)scratch;
+  float4* dst = (float4*)scratch + n4;
+#define JXL_IK(K) case K: if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)interfere_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+                          hipLaunchKernelGGL(interfere_kernel<K>, g, b, lds, s, scratch, ticks, src, dst, n4); break;
+  switch (kind) { JXL_IK(1) JXL_IK(2) JXL_IK(3) JXL_IK(4) JXL_IK(5) JXL_IK(6) default: break; }
+#undef JXL_IK
+}
+#endif
+
 }  // namespace jxlhip

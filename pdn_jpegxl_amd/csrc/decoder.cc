@@ -1031,7 +1031,8 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     // the layouts the two-pixels-per-lane kernels handle: even width; RGBA8 output with the alpha plane or RGB8 without one (bit 0: the Gaborish + first
     // iteration kernel, which for a two-iteration frame writes f32 rows whatever the output; bit 1: the second iteration's kernel)
     {
-      const bool even = d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs;
+      // (their buffer resources address 2 GB from a plane's base: larger planes take the general kernels)
+      const bool even = d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs && (uint64_t)d.wp * (uint64_t)d.hp * 4u < (1ull << 31);
       const bool rgba8 = d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply &&
                          ((d.nch_out == 4 && d.has_alpha) || (d.nch_out == 3 && d.ncolor == 3 && !d.has_alpha));   // RGBA8, or RGB8 without alpha
       d.stream_pairs = (even && (d.fused_gab_epf1 == 2 || rgba8) ? 1 : 0) | (even && d.fused_gab_epf1 == 2 && rgba8 ? 2 : 0);

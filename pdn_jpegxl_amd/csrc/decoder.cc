@@ -1028,13 +1028,14 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     d.final_stage = 4;
     for (int s = 0; s < 4; s++) if (d.stage_on[s]) d.final_stage = s;
     if (debug_taps) d.final_stage = 4;   // keep the filtered float planes for the stage taps; out_only_kernel converts
-    // the layouts the two-pixels-per-lane kernels handle: even width; RGBA8 output with the alpha plane or RGB8 without one (bit 0: the Gaborish + first
+    // the layouts the two-pixels-per-lane kernels handle: even width; 8-bit RGBA / RGB / gray + alpha / gray output (bit 0: the Gaborish + first
     // iteration kernel, which for a two-iteration frame writes f32 rows whatever the output; bit 1: the second iteration's kernel)
     {
       // (their buffer resources address 2 GB from a plane's base: larger planes take the general kernels)
       const bool even = d.fused_gab_epf1 && (d.w & 1) == 0 && d.w >= 8 && !no_stream_pairs && (uint64_t)d.wp * (uint64_t)d.hp * 4u < (1ull << 31);
-      const bool rgba8 = d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply &&
-                         ((d.nch_out == 4 && d.has_alpha) || (d.nch_out == 3 && d.ncolor == 3 && !d.has_alpha));   // RGBA8, or RGB8 without alpha
+      // 8-bit samples, sRGB or linear: RGBA, RGB, gray + alpha, gray (a frame's channel count is ncolor + has_alpha)
+      const bool rgba8 = d.out_bits == 8 && d.to_srgb <= 1 && !d.unpremultiply && (d.ncolor == 3 || d.ncolor == 1) &&
+                         d.nch_out == d.ncolor + (d.has_alpha ? 1 : 0) && !d.cmyk;
       d.stream_pairs = (even && (d.fused_gab_epf1 == 2 || rgba8) ? 1 : 0) | (even && d.fused_gab_epf1 == 2 && rgba8 ? 2 : 0);
     }
     if (d.fused_gab_epf1) {

@@ -912,19 +912,27 @@ struct PairConst {
   float gw0[3], gw1[3], gw2[3], cs[3], bsm;
   int w, h, wp, w8, y0, y1, r_end, band_y0;
   uint32_t in_bytes, cell_bytes, alpha_bytes, out_bytes;   // the lane's byte offsets inside a row: mirrored input pair, sigma cell, alpha pair, pair
-  bool outside, stores, to_float, use_alpha, xb_lo, xb_hi, rgb;   // rgb: three bytes per pixel out (no alpha channel)
+  bool outside, stores, to_float, use_alpha, xb_lo, xb_hi;
+  int bpp;   // bytes per output pixel: 4 RGBA, 3 RGB, 2 gray + alpha, 1 gray
 };
 struct PairAux { float is; uint32_t al; };
-// Two output pixels of a lane: 8 bytes RGBA, or 6 bytes RGB as three 16-bit stores (the pair starts on an even column: 2-byte aligned)
+// Two output pixels of a lane (p = R | G << 8 | B << 16 | A << 24 each): 8 bytes RGBA; 6 bytes RGB as three 16-bit stores (the pair starts
+// on an even column: 2-byte aligned); gray + alpha as one 32-bit store; gray as one 16-bit store (gray frames: R = G = B)
 __device__ __forceinline__ void StorePixelPair(const PairConst& k, uint32_t p0, uint32_t p1, int row) {
-  if (k.rgb) {
-    const uint32_t soff = (uint32_t)row * (uint32_t)k.w * 3u, v = (k.out_bytes >> 2) * 3u;
+  const uint32_t x = k.out_bytes >> 2;   // first column of the pair
+  if (k.bpp == 4) {
+    U2v px; px.x = p0; px.y = p1;
+    __builtin_amdgcn_raw_buffer_store_b64(px, k.out, k.out_bytes, (uint32_t)row * (uint32_t)k.w * 4u, 0);
+  } else if (k.bpp == 3) {
+    const uint32_t soff = (uint32_t)row * (uint32_t)k.w * 3u, v = x * 3u;
     __builtin_amdgcn_raw_buffer_store_b16((short)(p0 & 0xFFFFu), k.out, v, soff, 0);
     __builtin_amdgcn_raw_buffer_store_b16((short)(((p0 >> 16) & 0xFFu) | ((p1 & 0xFFu) << 8)), k.out, v + 2, soff, 0);
     __builtin_amdgcn_raw_buffer_store_b16((short)((p1 >> 8) & 0xFFFFu), k.out, v + 4, soff, 0);
+  } else if (k.bpp == 2) {
+    const uint32_t ga = ((p0 >> 8) & 0xFFu) | ((p0 >> 24) << 8) | (((p1 >> 8) & 0xFFu) << 16) | ((p1 >> 24) << 24);
+    __builtin_amdgcn_raw_buffer_store_b32(ga, k.out, x * 2u, (uint32_t)row * (uint32_t)k.w * 2u, 0);
   } else {
-    U2v px; px.x = p0; px.y = p1;
-    __builtin_amdgcn_raw_buffer_store_b64(px, k.out, k.out_bytes, (uint32_t)row * (uint32_t)k.w * 4u, 0);
+    __builtin_amdgcn_raw_buffer_store_b16((short)(((p0 >> 8) & 0xFFu) | (((p1 >> 8) & 0xFFu) << 8)), k.out, x, (uint32_t)row * (uint32_t)k.w, 0);
   }
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t PlaneResource(const void* p) {
@@ -1047,7 +1055,7 @@ __global__ __launch_bounds__(256, 4) void filter_stream_pairs_kernel(const DevIm
   k.stores = task && q >= 2 && q <= kStripLanes - 3 && X < k.w;
   k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;   // component 0 is column 0 of a block / component 1 is column 7
   k.use_alpha = im.has_alpha && !k.to_float;
-  k.rgb = im.nch_out == 3;
+  k.bpp = im.nch_out;
   k.in0 = PlaneResource(im.stream_in[0]); k.in1 = PlaneResource(im.stream_in[1]); k.in2 = PlaneResource(im.stream_in[2]);
   const bool no_gab = im.stream_no_gab != 0;
   k.sigma = PlaneResource(im.inv_sigma);
@@ -1207,7 +1215,7 @@ __global__ __launch_bounds__(256, 4) void filter_stream2_pairs_kernel(const DevI
   k.stores = task && q >= 1 && q <= kStripLanes - 2 && X < k.w;
   k.xb_lo = (X & 7) == 0; k.xb_hi = (X & 7) == 6;
   k.use_alpha = im.has_alpha != 0;
-  k.rgb = im.nch_out == 3;
+  k.bpp = im.nch_out;
   k.in0 = PlaneResource(im.stream_mid[0]); k.in1 = PlaneResource(im.stream_mid[1]); k.in2 = PlaneResource(im.stream_mid[2]);
   k.sigma = PlaneResource(im.inv_sigma);
   k.alpha = k.use_alpha ? PlaneResource(im.alpha) : k.in0;

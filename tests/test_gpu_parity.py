@@ -386,16 +386,16 @@ def test_scalar_unit_loops_match_the_vector_loops(gpu_decoder, oracle):
 
 @pytest.mark.parametrize("size", [(8, 8), (10, 40), (120, 131), (122, 20), (240, 9), (242, 140), (250, 300), (400, 259), (778, 531)])
 @pytest.mark.parametrize("distance", [1.0, 2.0])
-@pytest.mark.parametrize("layout", ["rgba", "rgb"])
+@pytest.mark.parametrize("layout", ["rgba", "rgb", "gray", "graya"])
 def test_filter_kernel_of_two_pixels_per_lane_matches_the_general_one(gpu_decoder, oracle, size, distance, layout):
-    """RGBA8 (with alpha) and RGB8 (without) frames of even width run Gaborish + the first EPF iteration in filter_stream_pairs_kernel
+    """8-bit RGBA / RGB / gray / gray + alpha frames of even width run Gaborish + the first EPF iteration in filter_stream_pairs_kernel
     (two pixels per lane, buffer addressing, mirrored edge pairs loaded from inside the frame); every other layout runs
     filter_stream_kernel.  The same streams through both - widths around the 120-column strips, one and two EPF iterations - must
-    give identical bytes for RGBA (both forms convert with v_cvt_pk_u8_f32) and the same pixels up to rounding ties for RGB (the general
-    form's three-byte path rounds half up), and match the oracle."""
+    give identical bytes for RGBA (both forms convert with v_cvt_pk_u8_f32) and the same pixels up to rounding ties for the other
+    layouts (the general form's paths round half up), and match the oracle."""
     w, h = size
     img = synth(w, h, 31 + w)
-    src = img if layout == "rgba" else np.ascontiguousarray(img[..., :3])
+    src = np.ascontiguousarray({"rgba": img, "rgb": img[..., :3], "gray": img[..., 1:2], "graya": img[..., [1, 3]]}[layout])
     data = oracle.encode(src, distance=distance)
     pairs = gpu_decode(gpu_decoder, [data])[0]
     try:

@@ -11,7 +11,7 @@ from pdn_jpegxl_amd.synth import synth
 img = synth(3840, 2160, 5)
 dec = api.Decoder(0)
 n = 48
-for layout, src in (("rgba", img), ("rgb", np.ascontiguousarray(img[..., :3])), ("gray", np.ascontiguousarray(img[..., 1:2]))):
+for layout, src in (("rgba", img), ("rgb", np.ascontiguousarray(img[..., :3])), ("gray", np.ascontiguousarray(img[..., 1:2])), ("graya", np.ascontiguousarray(img[..., [1, 3]]))):
     for dist in (1.0, 2.0):
         data = O.encode(src, distance=dist)
         out = torch.empty((n,) + src.shape, dtype=torch.uint8, device="cuda")

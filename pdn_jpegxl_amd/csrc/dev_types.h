@@ -66,7 +66,7 @@ enum ChanKind : int32_t {
 struct ChanDesc {
   int32_t kind;
   int32_t value;
-  int32_t pad0, pad1;
+  int32_t pad0, pad1;   // pad0: phase A writes 0; alpha_finish_gradient_kernel sets 1 on the groups it finished
 };
 
 // One coded channel of a Modular frame (sizes after Squeeze; shifts tell which sections code it).

@@ -1803,6 +1803,121 @@ __global__ __launch_bounds__(64) void alpha_ans_kernel(const DevImage* imgs, con
 }
 
 // Phase B: one wavefront per group: predictors (or plain conversion) -> 8-bit alpha plane.
+// ---- alpha planes whose rows all use the clamped gradient (what every encoder writes): the prediction pass as a register pipeline ----
+// A group's rows are a recurrence in both directions: a sample needs its West neighbour (same row) and North / North-West (row above).
+// Sixteen lanes (one DPP row) own one group.  Lane i takes rows i, 16 + i, 32 + i ...; a row is worked through in steps of 16 columns
+// (one 64-byte line of residuals, loaded whole and consumed from registers: no reliance on a cache keeping a line between uses, which
+// is what sank the first version of this pass - 404 MB of traffic per plane instead of 41); row r starts at step r, so that the
+// sixteen North samples of a step are exactly what the lane below (row r - 1) produced in the previous step: sixteen DPP row rotations.
+// A group is at most 16 steps wide, so a lane is never idle between its rows.  Four groups per wavefront.  No LDS, no tile staging:
+// ~13 vector instructions per sample instead of 62.  Groups this does not take (other predictors, widths that are not a multiple of 16,
+// deeper samples) are left to alpha_finish_kernel, which skips the groups taken here (ChanDesc::pad0).
+__device__ __forceinline__ int32_t RowRotateFromBelow(int32_t v) {   // value of lane i - 1 of the same row of 16 lanes (lane 0: lane 15)
+  return __builtin_amdgcn_update_dpp(0, v, 0x121 /* row_ror:1 */, 0xF, 0xF, false);
+}
+// whether rows [row0, row0 + step * k) ... of the group's alpha channel all end in a gradient leaf; called by `nlanes` lanes (lane index
+// `li`) that must then combine their answers
+__device__ __forceinline__ bool AlphaRowsAreGradient(const I4* tree, int sid, int gh, int li, int nlanes) {
+  bool ok = true;
+  for (int r = li; r < gh; r += nlanes) { bool u = false; ok = ok && (RowNode(tree, 0, sid, r, &u).a & 0xFF) == 5; }
+  return ok;
+}
+__device__ __forceinline__ bool AlphaGroupStatic(const DevImage& im, int g, int* gw, int* gh, int* sid, ChanDesc* d) {
+  // (a Modular frame has no alpha_desc, no group grid of this kind: nothing of it may be touched)
+  if (!im.has_alpha || im.is_modular || g < 0 || g >= im.ng || im.out_bits != 8 || im.alpha_bits != 8 || im.alpha_exp || (im.w & 3) != 0) return false;
+  const int gx = g % im.xg, gy = g / im.xg;
+  if (gy * kGroupDim >= im.band_y1 || (gy + 1) * kGroupDim <= im.band_y0) return false;   // outside the band: never decoded
+  *gw = min(kGroupDim, im.w - gx * kGroupDim); *gh = min(kGroupDim, im.h - gy * kGroupDim);
+  *sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  *d = im.alpha_desc[g];
+  return d->kind == kChanResid && (*gw & 15) == 0;
+}
+__global__ __launch_bounds__(64) void alpha_finish_gradient_kernel(const DevImage* __restrict__ imgs) {
+  const DevImage& im = imgs[blockIdx.y];
+  const int lane = threadIdx.x, sub = lane >> 4, li = lane & 15;
+  const int g = blockIdx.x * 4 + sub;
+  int gw = 0, gh = 0, sid = 0;
+  ChanDesc d;
+  d.kind = kChanFinal;
+  bool mine = AlphaGroupStatic(im, g, &gw, &gh, &sid, &d);
+  if (mine) mine = AlphaRowsAreGradient((const I4*)im.tree, sid, gh, li, 16);
+  {  // all sixteen lanes of the group must agree
+    const uint64_t bal = __ballot(mine);
+    mine = ((bal >> (sub * 16)) & 0xFFFFu) == 0xFFFFu;
+  }
+  if (__ballot(mine) == 0) return;
+  const int gx = mine ? g % im.xg : 0, gy = mine ? g / im.xg : 0;
+  const int x0 = gx * kGroupDim, y0 = gy * kGroupDim;
+  const int nq = mine ? gw >> 4 : 0, rows = mine ? gh : 0;
+  const JXL_GLB int32_t* const plane = G(im.alpha32) + (size_t)y0 * im.w + x0;
+  JXL_GLB uint8_t* const out = G(im.alpha) + (size_t)y0 * im.w + x0;
+  // uniform loop bound: the longest of the wavefront's groups
+  int steps = rows + 15;
+  steps = max(steps, __shfl_xor(steps, 16)); steps = max(steps, __shfl_xor(steps, 32));
+  typedef int32_t __attribute__((ext_vector_type(4))) I4v;
+  auto line_of = [&](int T, int* r_out, int* q_out) {   // the (row, 16-column step) this lane works on at time T; false: idle
+    const int m = T - li;
+    const int r = (m >> 4) * 16 + li, q = m & 15;
+    *r_out = r; *q_out = q;
+    return m >= 0 && r < rows && q < nq;
+  };
+  auto load_line = [&](int T, I4v* v) {   // the lane's residual line of time T (any in-range line when it is idle then)
+    int r, q;
+    const bool act = line_of(T, &r, &q);
+    const int rc = act ? r : 0, qc = act ? q : 0;
+    const JXL_GLB I4v* p = (const JXL_GLB I4v*)(plane + (size_t)(mine ? rc : 0) * im.w + qc * 16);
+    v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3];
+  };
+  if (mine && li == 0) im.alpha_desc[g].pad0 = 1;   // tells alpha_finish_kernel (the next launch) to leave the group alone
+  I4v cur[4], nxt[4];
+  load_line(0, nxt);
+  int32_t prev_out[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) prev_out[j] = 0;
+  int32_t W = 0, n_last = 0;
+  for (int T = 0; T < steps; T++) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = nxt[k];
+    load_line(T + 1, nxt);   // in flight during this step
+    int r, q;
+    const bool act = line_of(T, &r, &q);
+    int32_t nq16[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) nq16[j] = RowRotateFromBelow(prev_out[j]);   // row r - 1, the same 16 columns
+    const bool top = r == 0;
+    int32_t o[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const int32_t res = cur[j >> 2][j & 3];
+      int32_t n, nw;
+      if (top) { n = W; nw = W; }                       // top row: North = North-West = West
+      else { n = nq16[j]; nw = j == 0 ? n_last : nq16[j - 1]; }
+      if (j == 0 && q == 0) {                            // first column: West = North = North-West = the sample above (0 in the top row)
+        const int32_t w0 = top ? 0 : nq16[0];
+        W = w0; n = w0; nw = w0;
+      }
+      const int32_t val = (int32_t)((uint32_t)res + (uint32_t)ClampedGradient32(W, n, nw));
+      o[j] = val;
+      W = val;
+    }
+    n_last = nq16[15];
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) prev_out[j] = o[j];
+      uint32_t pk[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t wd = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) { const int32_t v = o[4 * k + b]; wd |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * b); }
+        pk[k] = wd;
+      }
+      typedef uint32_t __attribute__((ext_vector_type(4))) U4v;
+      *(JXL_GLB U4v*)(out + (size_t)r * im.w + q * 16) = U4v{pk[0], pk[1], pk[2], pk[3]};
+    }
+  }
+}
+
 __global__ __launch_bounds__(64, 3) void alpha_finish_kernel(const DevImage* __restrict__ imgs) {
   __shared__ int32_t s_carry[256];
   __shared__ int32_t s_tile[64 * 65];
@@ -1817,6 +1932,7 @@ __global__ __launch_bounds__(64, 3) void alpha_finish_kernel(const DevImage* __r
   const int gw = min(kGroupDim, im.w - x0), gh = min(kGroupDim, im.h - y0);
   int32_t* plane = im.alpha32 + (size_t)y0 * im.w + x0;
   const int sid = im.alpha_in_global ? 0 : 1 + 3 * im.nlf + kNumQuantTables + g;
+  if (d.pad0 == 1) return;   // finished by alpha_finish_gradient_kernel (phase A writes pad0 = 0)
   if (im.out_bits == 8 && im.alpha_bits == 8 && !im.alpha_exp) {   // the common case: clamp to u8, packed stores
     uint8_t* out = im.alpha + (size_t)y0 * im.w + x0;
     if (d.kind == kChanResid) {
@@ -2225,6 +2341,7 @@ void LaunchModularOut(const DevImage* imgs, int nimg, size_t max_pixels, hipStre
 
 void LaunchAlphaFinish(const DevImage* imgs, int nimg, int max_groups, hipStream_t s) {
   if (nimg <= 0 || max_groups <= 0) return;
+  hipLaunchKernelGGL(alpha_finish_gradient_kernel, dim3((max_groups + 3) / 4, nimg), dim3(64), 0, s, imgs);
   hipLaunchKernelGGL(alpha_finish_kernel, dim3(max_groups, nimg), dim3(64), 0, s, imgs);
 }
 

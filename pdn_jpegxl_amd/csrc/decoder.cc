@@ -460,6 +460,9 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     size_t orient_tmp = 0;   // frames with an orientation other than 1 are decoded here, then laid out as displayed in the caller's buffer
   };
   std::vector<PerImg> L((size_t)n);
+  // the images' status words (64 B each) lie side by side: ONE copy brings them back (a copy per image was 384 five-microsecond copy
+  // kernels at the end of the pixel stream - 2 ms of the step - and as many API calls)
+  const size_t z_status_base = ws_zero.Take((size_t)std::max(1, n) * 64);
   int total_lf = 0, total_groups = 0, n_mod_tasks = 0;
   // Modular frames whose MA tree looks at decoded neighbours take the generic per-lane path: give it LDS row buffers (groups of up to
   // 256 columns); with the weighted predictor its per-sample state goes to LDS as well, which limits a workgroup to 8 sections
@@ -509,7 +512,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       // Modular (lossless) frame: whole-image int32 channel planes, no VarDCT workspace
       const bool resident_m = dev_data && dev_data[i] && f.cs_contiguous;
       l.cs = resident_m ? 0 : blob.Take(f.cs_size + 16);
-      l.z_status = ws_zero.Take(64);
+      l.z_status = z_status_base + (size_t)i * 64;
       for (auto& pl : f.mod_planes) l.mod_planes.push_back(ws.Take(4 * (size_t)std::max(1, pl.w) * std::max(1, pl.h)));
       const size_t nsec = 1 + (size_t)f.nlf + f.ng;
       l.mod_chan = blob.Take(sizeof(ModChanDev) * f.mod_coded.size());
@@ -537,7 +540,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     l.cs = resident ? 0 : blob.Take(f.cs_size + 16);
     if (PlanColor(f).transfer == 5) l.trc_lut = blob.Take(4 * 3 * 4096, 256) + 1;
     l.z_cellinfo = ws_zero.Take(4 * cells);
-    l.z_status = ws_zero.Take(64);
+    l.z_status = z_status_base + (size_t)i * 64;
     {
       // entry lists of the decoded group rows only (a band decode touches a band's worth), block index for the whole cell grid
       int b0 = 0, b1 = (int)f.yg;
@@ -1265,9 +1268,7 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
       LaunchOrient(imgs[i].out, dev_out[i], (int)f.xsize, (int)f.ysize, (f.ncolor + (f.black_index >= 0 ? 1 : 0) + (f.alpha_index >= 0 ? 1 : 0)) * (int)OutBytesPerSample(f),
                    (int)f.orientation, stream);
     }
-  for (int i = 0; i < n; i++)
-    if (parse_status[i] == DecoderStatus_Ok)
-      HIP_OK(hipMemcpyAsync(h_status + (size_t)i * 16, d_ws + status_off[i], 64, hipMemcpyDeviceToHost, stream));
+  LaunchStatusToHost((const uint32_t*)(d_ws + z_status_base), h_status, n * 16, stream);   // (images that failed to parse: zeros)
   HIP_OK(hipEventRecord(S.done, stream));
   HIP_OK(hipGetLastError());
   last_stream = stream;

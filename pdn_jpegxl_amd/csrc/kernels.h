@@ -41,6 +41,8 @@ void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float
 void LaunchFilterTiles(const DevImage* imgs, int nimg, int max_w, int max_h, int stage_mask, bool any_unfiltered,
                        int any_fused, int any_fused2, hipStream_t s);
 
+// the batch's status words into pinned host memory, by a kernel (kernels.hip)
+void LaunchStatusToHost(const uint32_t* src, uint32_t* dst_pinned, int nwords, hipStream_t s);
 #ifdef JXLHIP_EXPERIMENTS
 // occupies one kind of resource for `ms` milliseconds on stream s (kernels.hip, interference probes)
 void LaunchInterference(int kind, int wg_per_cu, int lds_kb, float ms, float* scratch, size_t scratch_bytes, hipStream_t s);

@@ -6,10 +6,15 @@
 //                         >= 16 points on v_mfma_f32_16x16x4_f32), f32 XYB out (12 B/px).  Tiles that hold part of a varblock larger
 //                         than the tile, a special 8x8 transform or a progressive frame go to a per-image list for the generic
 //                         (unfused, any-size) kernels of kernels.hip.
-//   filter_stream_kernel  Gaborish + one / two EPF iterations + XYB -> output samples in one register-streaming kernel (DPP wave shifts).
+//   filter_stream_kernel, filter_stream2_kernel
+//                         Gaborish + EPF iteration 1 (+ colour and output, or f32 rows for) iteration 2 + colour and output: register
+//                         streaming with DPP wave shifts, four pixels per lane, any width and output layout.
+//   filter_stream_pairs_kernel, filter_stream2_pairs_kernel
+//                         the same for frames of even width with 8-bit output (RGBA, RGB, gray + alpha, gray): two pixels per lane,
+//                         buffer addressing, no load in a branch, four / eight wavefronts per SIMD.
 //   filter_tile_kernel    one Gaborish / EPF stage on a 64x32 tile + halo staged in LDS (mirrored at the frame edge); the LAST
-//                         enabled stage of an image converts XYB -> output samples and merges alpha.  Used for what the streaming
-//                         kernel does not cover.
+//                         enabled stage of an image converts XYB -> output samples and merges alpha.  Used for frames without EPF
+//                         (Gaborish alone), for Gaborish and iteration 0 of three-iteration frames, and for the stage taps.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include "dev_types.h"

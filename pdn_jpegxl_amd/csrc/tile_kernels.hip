@@ -43,8 +43,8 @@ __device__ const uint8_t t_quant_table[kNumStrategies] = {0, 1, 2, 3, 4, 5, 6, 6
 
 __device__ __forceinline__ bool Special(uint32_t s) { return (s >= 1 && s <= 3) || (s >= 12 && s <= 17); }
 typedef float __attribute__((ext_vector_type(4))) F4;
-// a 16x16 sub-block (2x2 cells at even cell coordinates) goes to the matrix cores when the varblock of its top-left cell is at
-// least 16 points in both directions (varblocks are aligned to their size, so the sub-block then lies inside that one varblock)
+// a 16x16 sub-block (2x2 cells at even cell coordinates) goes to the matrix cores, per pass, when the varblocks of its cells are at
+// least 16 points long in the pass's direction, of one length and at one offset (MfmaRows / MfmaCols below)
 // One 16x16 output sub-block: acc = sum_k A[k] * B[k] with both operand streams fetched up front (N / 4 independent loads
 // each, one wait) so that the MFMA chain is not paced by a memory round trip per step.  pa / pb: lane's first operand;
 // sa / sb: stride between consecutive k-steps of four.
@@ -58,27 +58,10 @@ __device__ __forceinline__ F4 MfmaChain(const float* pa, int sa, const float* pb
   for (int k = 0; k < N / 4; k++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[k], b[k], acc, 0, 0, 0);
   return acc;
 }
-// The same with one operand stream read from the k-contiguous basis table (basis_mfma: for a lane (n, q) the N / 4 values
-// basis[(4 k + q) * N + n], k = 0 .. N/4-1, lie side by side): N / 16 sixteen-byte loads and one address instead of N / 4 loads with
-// an address each (64-point passes: 16 global loads and as many 64-bit address sums per sub-block).
-template <int N, bool kTableIsA>
-__device__ __forceinline__ F4 MfmaChainT(const float* table, const float* po, int so) {
-  float t[N / 4], o[N / 4];
-#pragma unroll
-  for (int k = 0; k < N / 16; k++) {
-    const float4 v = *(const float4*)(table + 4 * k);
-    t[4 * k] = v.x; t[4 * k + 1] = v.y; t[4 * k + 2] = v.z; t[4 * k + 3] = v.w;
-  }
-#pragma unroll
-  for (int k = 0; k < N / 4; k++) o[k] = po[k * so];
-  F4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int k = 0; k < N / 4; k++)
-    acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
-  return acc;
-}
-// The 32-point table from an LDS copy (two arrays of 16-byte halves, so that consecutive (n, q) lanes read consecutive 16 bytes): the
-// global-memory table cost every 16x16 sub-block two dependent L2 round trips before its first MFMA.
+// 32- and 64-point passes: one operand stream is the k-contiguous basis table (basis_mfma: for a lane (n, q) the N / 4 values
+// basis[(4 k + q) * N + n], k = 0 .. N/4-1, lie side by side), read from an LDS copy (arrays of 16-byte pieces, so that consecutive
+// (n, q) lanes read consecutive 16 bytes): from global memory every 16x16 sub-block paid two to four dependent L2 round trips before
+// its first MFMA.
 template <bool kTableIsA>
 __device__ __forceinline__ F4 MfmaChain32L(const float4* t_lo, const float4* t_hi, int pair, const float* po, int so) {
   const float4 v0 = t_lo[pair], v1 = t_hi[pair];
@@ -92,14 +75,34 @@ __device__ __forceinline__ F4 MfmaChain32L(const float4* t_lo, const float4* t_h
     acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
   return acc;
 }
-// offset of the N-point table inside basis_mfma (N = 32, 64), and of lane (n, q)'s run
-__device__ __forceinline__ const float* MfmaTable(const float* basis_mfma, int N, int n, int q) {
-  return basis_mfma + (N == 32 ? 0 : 1024) + (n * 4 + q) * (N / 4);
+// The 64-point table likewise (four arrays of 16-byte quarters; staged only by tiles that hold a 64-point varblock): from global
+// memory a sub-block paid four dependent L2 round trips before its sixteen MFMAs, and a fifth of this content's area is 64 points long.
+template <bool kTableIsA>
+__device__ __forceinline__ F4 MfmaChain64L(const float4* t64, int pair, const float* po, int so) {
+  float t[16], o[16];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float4 v = t64[j * 256 + pair];
+    t[4 * j] = v.x; t[4 * j + 1] = v.y; t[4 * j + 2] = v.z; t[4 * j + 3] = v.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) o[k] = po[k * so];
+  F4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    acc = kTableIsA ? __builtin_amdgcn_mfma_f32_16x16x4f32(t[k], o[k], acc, 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x4f32(o[k], t[k], acc, 0, 0, 0);
+  return acc;
 }
-__device__ __forceinline__ F4 MfmaChainN(int n, const float* pa, int sa, const float* pb, int sb) {
-  return n == 16 ? MfmaChain<16>(pa, sa, pb, sb) : (n == 32 ? MfmaChain<32>(pa, sa, pb, sb) : MfmaChain<64>(pa, sa, pb, sb));
+// Per pass, a 16x16 sub-block only needs ONE transform length and phase over its 16 columns (vertical pass) or rows (horizontal pass):
+// the two cells across the pass direction must belong to varblocks of the same length in that direction, at the same offset - they
+// need not be the same varblock (16x8 blocks side by side, a 32x16 beside a 32x32 ...).  With the one-varblock test alone, every
+// rectangular block of 8 points in the other direction fell back to the vector-ALU loops (a fifth of this content's cells).
+__device__ __forceinline__ bool MfmaRows(uint32_t tl, uint32_t tr) {   // vertical pass: rows >= 16, same length and row offset
+  return (tl >> 31) && (tr >> 31) && ((tl >> 21) & 7) >= 1 && ((tl >> 21) & 7) == ((tr >> 21) & 7) && ((tl >> 13) & 31) == ((tr >> 13) & 31);
 }
-__device__ __forceinline__ bool MfmaSubBlock(uint32_t info) { return (info >> 31) && ((info >> 18) & 7) >= 1 && ((info >> 21) & 7) >= 1; }
+__device__ __forceinline__ bool MfmaCols(uint32_t tl, uint32_t bl) {   // horizontal pass: columns >= 16, same length and column offset
+  return (tl >> 31) && (bl >> 31) && ((tl >> 18) & 7) >= 1 && ((tl >> 18) & 7) == ((bl >> 18) & 7) && ((tl >> 8) & 31) == ((bl >> 8) & 31);
+}
 __device__ __forceinline__ int Mirror(int v, int n) {
   while (v < 0 || v >= n) v = v < 0 ? -v - 1 : 2 * n - 1 - v;
   return v;
@@ -280,6 +283,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
   const U32x2** csc = (const U32x2**)(ctot + 4);       // 64   scan list of the cell's quant table
   float4* t32_lo = (float4*)(csc + 64);                // 128  k-contiguous 32-point basis, first / second four k-steps of lane (n, q) = [n * 4 + q]
   float4* t32_hi = t32_lo + 128;                       // 128
+  float4* t64 = t32_hi + 128;                          // 4 x 256  the 64-point basis, quarter j of lane (n, q) = [j * 256 + n * 4 + q]
   const DevImage& im = imgs[blockIdx.y];
   const int tile = blockIdx.x;
   if (tile >= im.wt * im.ht) return;
@@ -294,7 +298,7 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
     float4* z = (float4*)cfc3;
     for (int i = tid; i < 3 * kTileF / 4; i += 768) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  int bad = 0;
+  int bad = 0, has64 = 0;
   if (tid < 64) {
     const int cx = tx * 8 + (tid & 7), cy = ty * 8 + (tid >> 3);
     const bool inside = cx < im.w8 && cy < im.h8;
@@ -319,6 +323,11 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
       }
     }
     const bool valid = (info >> 31) && !bad;
+    has64 = valid && (lcx == 3 || lcy == 3);
+    {  // (wavefront 0 is the only writer of the per-cell tables; the flag travels with them through the barrier below)
+      const uint64_t any = __ballot(has64);
+      if (tid == 0) ctot[3] = any != 0;
+    }
     const uint32_t q = t_quant_table[valid ? (info & 0xFF) : 0];
     const uint32_t rq_origin = (uint32_t)__shfl((int)rqv, valid ? tid - iy * 8 - ix : tid);
     const uint32_t lng = 3 + max(lcx, lcy);
@@ -362,6 +371,9 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
   if (__syncthreads_or(bad)) {
     if (tid == 0) im.tile_list[atomicAdd(&im.status[1], 1u)] = (uint32_t)tile;
     return;
+  }
+  if (ctot[3]) {   // the tile holds a 64-point varblock: stage that table (16 KB; the barrier before the passes covers it)
+    for (int i = tid; i < 1024; i += 768) t64[(i & 3) * 256 + (i >> 2)] = ((const float4*)(basis_mfma + 1024))[i];
   }
   const float* const Bl = basis_all;
   float* const cfc = cfc3 + team * kTileF;   // this team's tile
@@ -446,19 +458,19 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
 #pragma unroll
     for (int rb = 0; rb < 4; rb++) {
       const uint32_t inf = ci[rb * 16 + tw * 2];
-      m[rb] = MfmaSubBlock(inf);   // wave-uniform
+      m[rb] = MfmaRows(inf, ci[rb * 16 + tw * 2 + 1]);   // wave-uniform
       if (m[rb]) {
         const int iy = (inf >> 13) & 31, lcy = (inf >> 21) & 7, R = 8 << lcy;
         const float* cp = cfc + ((rb * 2 - iy) * 8 + lq) * kLP + x0 + l16;
         if (R == 16) acc[rb] = MfmaChain<16>(B816 + 64 + lq * 16 + iy * 8 + l16, 64, cp, 4 * kLP);
         else if (R == 32) acc[rb] = MfmaChain32L<true>(t32_lo, t32_hi, (iy * 8 + l16) * 4 + lq, cp, 4 * kLP);
-        else acc[rb] = MfmaChainT<64, true>(MfmaTable(basis_mfma, 64, iy * 8 + l16, lq), cp, 4 * kLP);
+        else acc[rb] = MfmaChain64L<true>(t64, (iy * 8 + l16) * 4 + lq, cp, 4 * kLP);
       }
     }
     // the rest on the vector ALUs.  One lane = two adjacent columns x one 8-row cell: every basis fetch feeds 16 FMAs.
     const int x = x0 + (lane & 7) * 2, cr = lane >> 3;
     const uint32_t info = ci[cr * 8 + (x >> 3)];
-    const bool valu = (info >> 31) && !MfmaSubBlock(ci[(cr >> 1) * 16 + (x >> 4) * 2]);
+    const bool valu = (info >> 31) && !MfmaRows(ci[(cr >> 1) * 16 + (x >> 4) * 2], ci[(cr >> 1) * 16 + (x >> 4) * 2 + 1]);
     float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valu) {
       const int iy = (info >> 13) & 31, lcy = (info >> 21) & 7;
@@ -499,19 +511,19 @@ __global__ __launch_bounds__(768, 6) void recon_tile_kernel(const DevImage* __re
 #pragma unroll
     for (int cs = 0; cs < 4; cs++) {
       const uint32_t inf = ci[tw * 16 + cs * 2];
-      m[cs] = MfmaSubBlock(inf);
+      m[cs] = MfmaCols(inf, ci[tw * 16 + 8 + cs * 2]);
       if (m[cs]) {
         const int ix = (inf >> 8) & 31, lcx = (inf >> 18) & 7, C = 8 << lcx;
         const float* ap = cfc + (y0 + l16) * kLP + (cs * 2 - ix) * 8 + lq;
         if (C == 16) acc[cs] = MfmaChain<16>(ap, 4, B816 + 64 + lq * 16 + ix * 8 + l16, 64);
         else if (C == 32) acc[cs] = MfmaChain32L<false>(t32_lo, t32_hi, (ix * 8 + l16) * 4 + lq, ap, 4);
-        else acc[cs] = MfmaChainT<64, false>(MfmaTable(basis_mfma, 64, ix * 8 + l16, lq), ap, 4);
+        else acc[cs] = MfmaChain64L<false>(t64, (ix * 8 + l16) * 4 + lq, ap, 4);
       }
     }
     // the rest: two adjacent rows per lane
     const int y = y0 + (lane & 7) * 2, cc = lane >> 3;
     const uint32_t info = ci[(y >> 3) * 8 + cc];
-    const bool valu = (info >> 31) && !MfmaSubBlock(ci[(y >> 4) * 16 + (cc >> 1) * 2]);
+    const bool valu = (info >> 31) && !MfmaCols(ci[(y >> 4) * 16 + (cc >> 1) * 2], ci[(y >> 4) * 16 + 8 + (cc >> 1) * 2]);
     float a0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (valu) {
       const int ix = (info >> 8) & 31, lcx = (info >> 18) & 7;
@@ -1287,7 +1299,7 @@ __global__ void out_only_kernel(const DevImage* __restrict__ imgs) {
 void LaunchReconTiles(const DevImage* imgs, int nimg, int max_tiles, const float* basis_all, const float* basis_small,
                       const float* llf_scale, const float* basis_mfma, hipStream_t s) {
   // three tiles, B816, four per-cell words + 2 x 3 prefix words per cell, totals, per-cell scan-list pointers
-  const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128 + 1024) * 4;   // + the 32-point matrix-core table
+  const size_t lds = (size_t)(3 * kTileF + 320 + 64 * 4 + 64 * 6 + 4 + 128 + 1024 + 4096) * 4;   // + the 32- and 64-point matrix-core tables
   static bool raised = false;
   if (!raised) { (void)hipFuncSetAttribute((const void*)recon_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); raised = true; }
   hipLaunchKernelGGL(recon_tile_kernel, dim3(max_tiles, nimg), dim3(768), lds, s, imgs, basis_all, basis_small, llf_scale, basis_mfma);

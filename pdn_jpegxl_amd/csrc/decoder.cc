@@ -1214,9 +1214,10 @@ void JxlHipDecoder::Decode(int32_t n_, const uint8_t* const* host_data, const si
     HIP_OK(hipStreamSynchronize(stream));
     CopyPlaneTap(0);
   }
-  // the alpha planes' prediction pass: on the pixel stream of ITS batch rather than behind the token pass on the HF stream, which is
-  // the longest of the three chains (knob JXLHIP_ALPHA_FINISH_ON_HF: the old placement)
-  const bool finish_on_hf = s_hf == stream || debug_taps || Knob("JXLHIP_ALPHA_FINISH_ON_HF");
+  // the alpha planes' prediction pass: behind the token pass on the HF stream (the pixel stream is the longest of the three chains
+  // since the reconstruction workgroup grew to 72 KB of LDS and the HF kernel keeps its residency beside it: 107.2 against 108.7 ms;
+  // while the HF stream was the longest it was the other way round - knob JXLHIP_ALPHA_FINISH_ON_PIX)
+  const bool finish_on_hf = s_hf == stream || debug_taps || !Knob("JXLHIP_ALPHA_FINISH_ON_PIX");
   if (finish_on_hf) {
     if (any_alpha && !(skip_stages & 4)) LaunchAlphaFinish(d_imgs, n, max_groups, s_hf);
     Mark("alpha_finish", s_hf, 1);

@@ -352,11 +352,18 @@ void JxlHipDecoder::WaitSlot(Slot& S) {
   if (!S.pending) return;
   HIP_OK(hipEventSynchronize(S.done));
   S.pending = false;
-  S.stage_ms.assign(S.stage_names.size(), 0.f);
-  for (size_t i = 1; i < S.stage_names.size(); i++)
-    if (S.stage_chain[i] == S.stage_chain[i - 1]) (void)hipEventElapsedTime(&S.stage_ms[i], S.events[i - 1], S.events[i]);
+  // a stage's time = from the previous mark of ITS chain (stream) to its own; marks of different chains may interleave in the list
+  S.stage_ms.assign(S.stage_names.size(), -1.f);
+  {
+    int last_of[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (size_t i = 0; i < S.stage_names.size(); i++) {
+      const int c = S.stage_chain[i] & 7;
+      if (last_of[c] >= 0) { S.stage_ms[i] = 0.f; (void)hipEventElapsedTime(&S.stage_ms[i], S.events[last_of[c]], S.events[i]); }
+      last_of[c] = (int)i;
+    }
+  }
   for (size_t i = 1; i < S.stage_names.size(); i++) {
-    if (S.stage_chain[i] != S.stage_chain[i - 1]) continue;
+    if (S.stage_ms[i] < 0.f) continue;   // the first mark of a chain: a start, not a stage
     size_t k = 0;
     while (k < total_names.size() && total_names[k] != S.stage_names[i]) k++;
     if (k == total_names.size()) { total_names.push_back(S.stage_names[i]); total_ms.push_back(0.0); }
@@ -1577,7 +1584,7 @@ int32_t jxlhip_stage_times(JxlHipDecoder* dec, const char** names, float* ms, in
   JxlHipDecoder::Slot& S = dec->Last();
   int32_t k = 0;
   for (size_t i = 1; i < S.stage_names.size() && i < S.stage_ms.size() && k < capacity; i++) {
-    if (S.stage_chain[i] != S.stage_chain[i - 1]) continue;
+    if (S.stage_ms[i] < 0.f) continue;
     if (names) names[k] = S.stage_names[i].c_str();
     if (ms) ms[k] = S.stage_ms[i];
     k++;
